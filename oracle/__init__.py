@@ -1,0 +1,131 @@
+"""ctypes binding of oracle/libnd4_oracle.so — *** TEST INFRASTRUCTURE ***.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (nd4js_amd, libnd4hip.so) never does. See oracle/nd4_oracle.h for the
+reference file:line each function restates; parity is pinned by tests/test_oracle_golden.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnd4_oracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_i64 = ctypes.c_int64
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("nd4_oracle.c", "nd4_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.nd4o_uniform.restype = ctypes.c_double
+        L.nd4o_uniform.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.nd4o_fill_uniform.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _i64, _dp]
+        L.nd4o_matmul2.restype = ctypes.c_int
+        L.nd4o_matmul2.argtypes = [ctypes.c_int, _ip, _dp, ctypes.c_int, _ip, _dp, _ip, _dp]
+        L.nd4o_matmul_batched.argtypes = [_i64, _i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
+        L.nd4o_qr_decomp_full.argtypes = [_i64, _i64, _i64, _dp, _dp, _dp]
+        L.nd4o_qr_decomp.argtypes = [_i64, _i64, _i64, _dp, _dp, _dp]
+        L.nd4o_lu_decomp.argtypes = [_i64, _i64, _dp, _dp, _ip]
+        L.nd4o_svd_jac_2sided.restype = ctypes.c_int
+        L.nd4o_svd_jac_2sided.argtypes = [_i64, _i64, _dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def fill_uniform(seed, n, offset=0):
+    out = np.empty(int(n), dtype=np.float64)
+    lib().nd4o_fill_uniform(seed, offset, out.size, _d(out))
+    return out
+
+
+def matmul2(a, b):
+    a, b = _f64(a), _f64(b)
+    if a.ndim < 2:
+        raise ValueError("A must be at least 2D.")
+    if b.ndim < 2:
+        raise ValueError("B must be at least 2D.")
+    sa = np.asarray(a.shape, dtype=np.int32)
+    sb = np.asarray(b.shape, dtype=np.int32)
+    nd = max(a.ndim, b.ndim)
+    lead = np.broadcast_shapes(a.shape[:-2], b.shape[:-2]) if a.shape[-1] == b.shape[-2] else ()
+    sc = np.zeros(nd, dtype=np.int32)
+    c = np.empty(tuple(lead) + (a.shape[-2], b.shape[-1]), dtype=np.float64)
+    rc = lib().nd4o_matmul2(a.ndim, _i(sa), _d(a), b.ndim, _i(sb), _d(b), _i(sc), _d(c))
+    if rc == -1:
+        raise ValueError("The last dimension of A and the 2nd to last dimension of B do not match.")
+    if rc == -2:
+        raise ValueError("Shapes are not broadcast-compatible.")
+    assert tuple(sc) == c.shape, (tuple(sc), c.shape)
+    return c
+
+
+def qr_decomp_full(a):
+    a = _f64(a)
+    M, N = a.shape[-2:]
+    batch = int(np.prod(a.shape[:-2], dtype=np.int64))
+    q = np.empty(a.shape[:-2] + (M, M))
+    r = np.empty(a.shape[:-2] + (M, N))
+    lib().nd4o_qr_decomp_full(batch, M, N, _d(a), _d(q), _d(r))
+    return q, r
+
+
+def qr_decomp(a):
+    a = _f64(a)
+    M, N = a.shape[-2:]
+    L = min(M, N)
+    batch = int(np.prod(a.shape[:-2], dtype=np.int64))
+    q = np.empty(a.shape[:-2] + (M, L))
+    r = np.empty(a.shape[:-2] + (L, N))
+    lib().nd4o_qr_decomp(batch, M, N, _d(a), _d(q), _d(r))
+    return q, r
+
+
+def lu_decomp(a):
+    a = _f64(a)
+    N = a.shape[-1]
+    if a.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    batch = int(np.prod(a.shape[:-2], dtype=np.int64))
+    lu = np.empty_like(a)
+    p = np.empty(a.shape[:-1], dtype=np.int32)
+    lib().nd4o_lu_decomp(batch, N, _d(a), _d(lu), _i(p))
+    return lu, p
+
+
+def svd_jac_2sided(a):
+    """Square input only (the reference's rectangular pre-reduction is a host composition)."""
+    a = _f64(a)
+    N = a.shape[-1]
+    assert a.shape[-2] == N
+    batch = int(np.prod(a.shape[:-2], dtype=np.int64))
+    u = np.empty_like(a)
+    v = np.empty_like(a)
+    sv = np.empty(a.shape[:-1])
+    sweeps = lib().nd4o_svd_jac_2sided(batch, N, _d(a), _d(u), _d(sv), _d(v))
+    return u, sv, v, sweeps

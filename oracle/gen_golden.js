@@ -1,0 +1,217 @@
+#!/usr/bin/env node
+/* Golden-vector generator (TEST INFRASTRUCTURE — runs only in the build container).
+ *
+ * Loads the real reference bundle (/root/reference/dist/nd.js, webpack build of
+ * src/help.js -> src/la/*.js), feeds it inputs from the repo's counter-based
+ * generator `nd4_uniform(seed, idx)` (bit-identical twins: oracle/nd4_oracle.c,
+ * nd4js_amd/rng.py, nd4js_amd/csrc/fill.hip) and stores ONLY numbers (outputs,
+ * sampled entries, norms) as .npy files + manifest.json under tests/golden/.
+ * Nothing of the reference's source is written anywhere.
+ *
+ *   node oracle/gen_golden.js small            # C1 + mid + edge families (seconds)
+ *   node oracle/gen_golden.js c2               # 4096^2 matmul samples   (~2 min)
+ *   node oracle/gen_golden.js c3               # 2048^2 QR + LU samples  (~20 s)
+ *   node oracle/gen_golden.js c4               # 2048^2 SVD sv + samples (~70 s)
+ *   node oracle/gen_golden.js c5 [stride]      # 512^2 SVDs of every `stride`-th batch member
+ */
+'use strict';
+const fs = require('fs'), path = require('path');
+const REF = process.env.ND4_REFERENCE || '/root/reference/dist/nd.js';
+const nd = require(REF);
+const OUT = path.join(__dirname, '..', 'tests', 'golden');
+fs.mkdirSync(OUT, {recursive: true});
+
+/* ---------- counter-based generator (32-bit ops only) ---------- */
+function fmix32(h) {
+  h ^= h >>> 16; h = Math.imul(h, 0x85ebca6b);
+  h ^= h >>> 13; h = Math.imul(h, 0xc2b2ae35);
+  h ^= h >>> 16; return h >>> 0;
+}
+function nd4_uniform(seed, idx) {            // -> [-1, 1), multiple of 2^-52
+  const hi = fmix32((idx ^ fmix32(seed >>> 0)) >>> 0);
+  const lo = fmix32((hi + 0x9E3779B9 + idx) >>> 0);
+  const m = (hi >>> 5) * 67108864 + (lo >>> 6);      // 27 + 26 = 53 bits
+  return m * 2.220446049250313e-16 - 1.0;            // 2*m*2^-53 - 1
+}
+function fill(seed, n, off = 0) {
+  const a = new Float64Array(n);
+  for (let i = 0; i < n; i++) a[i] = nd4_uniform(seed, off + i);
+  return a;
+}
+function hashIdx(seed, i, mod) { return fmix32((fmix32(seed) + Math.imul(i, 0x9E3779B1)) >>> 0) % mod; }
+
+/* ---------- npy writer ---------- */
+function npy(name, typed, shape) {
+  const descr = typed instanceof Float64Array ? '<f8' : typed instanceof Int32Array ? '<i4' : null;
+  if (!descr) throw new Error('dtype');
+  let hdr = `{'descr': '${descr}', 'fortran_order': False, 'shape': (${shape.join(', ')}${shape.length === 1 ? ',' : ''}), }`;
+  const pad = 64 - ((10 + hdr.length + 1) % 64);
+  hdr += ' '.repeat(pad % 64) + '\n';
+  const head = Buffer.alloc(10);
+  head.write('\x93NUMPY', 0, 'latin1'); head[6] = 1; head[7] = 0; head.writeUInt16LE(hdr.length, 8);
+  const body = Buffer.from(typed.buffer, typed.byteOffset, typed.byteLength);
+  fs.writeFileSync(path.join(OUT, name + '.npy'), Buffer.concat([head, Buffer.from(hdr, 'latin1'), body]));
+}
+const NDA = (shape, data) => new nd.NDArray(Int32Array.from(shape), data);
+
+const manifestPath = path.join(OUT, 'manifest.json');
+const manifest = fs.existsSync(manifestPath) ? JSON.parse(fs.readFileSync(manifestPath)) : {rng: 'fmix32-v1', cases: {}};
+function record(name, meta, tensors) {
+  const files = {};
+  for (const [k, [typed, shape]] of Object.entries(tensors)) { npy(`${name}.${k}`, typed, shape); files[k] = `${name}.${k}.npy`; }
+  manifest.cases[name] = Object.assign({}, meta, {files});
+  fs.writeFileSync(manifestPath, JSON.stringify(manifest, null, 1));
+  console.log('wrote', name);
+}
+function fro(a) { let s = 0; for (let i = 0; i < a.length; i++) s += a[i] * a[i]; return Math.sqrt(s); }
+
+/* ---------- input families (mirroring the reference tests' families) ---------- */
+function applyFamily(fam, a, M, N, seed) {
+  switch (fam) {
+    case 'dense': break;
+    case 'sparse10':                       // ~10 % exact zeros (qr_test.js:93-104 family)
+      for (let i = 0; i < a.length; i++) if (hashIdx(seed + 77, i, 10) === 0) a[i] = 0; break;
+    case 'zerorow': { const r = hashIdx(seed + 78, 0, M); for (let j = 0; j < N; j++) a[r * N + j] = 0; break; }
+    case 'zerocol': { const c = hashIdx(seed + 79, 0, N); for (let i = 0; i < M; i++) a[i * N + c] = 0; break; }
+    case 'rankdef': {                      // rows r >= rank are copies/combinations of the first rows
+      const rank = Math.max(1, Math.min(M, N) >> 1);
+      for (let i = rank; i < M; i++) for (let j = 0; j < N; j++)
+        a[i * N + j] = 0.5 * a[((i - rank) % rank) * N + j] - 0.25 * a[((i + 1) % rank) * N + j];
+      break; }
+    case 'diag': for (let i = 0; i < M; i++) for (let j = 0; j < N; j++) if (i !== j) a[i * N + j] = 0; break;
+    case 'triu': for (let i = 0; i < M; i++) for (let j = 0; j < i && j < N; j++) a[i * N + j] = 0; break;
+    default: throw new Error(fam);
+  }
+  return a;
+}
+
+function caseMatmul(name, seedA, seedB, shapeA, shapeB) {
+  const nA = shapeA.reduce((a, b) => a * b, 1), nB = shapeB.reduce((a, b) => a * b, 1);
+  const C = nd.la.matmul2(NDA(shapeA, fill(seedA, nA)), NDA(shapeB, fill(seedB, nB)));
+  record(name, {op: 'matmul2', seedA, seedB, shapeA, shapeB, shapeC: Array.from(C.shape)}, {C: [C.data, Array.from(C.shape)]});
+}
+function caseQR(name, seed, shape, fam = 'dense', fn = 'qr_decomp') {
+  const M = shape[shape.length - 2], N = shape[shape.length - 1], n = shape.reduce((a, b) => a * b, 1);
+  const a = fill(seed, n);
+  for (let o = 0, b = 0; o < n; o += M * N, b++) applyFamily(fam, a.subarray(o, o + M * N), M, N, seed + b);
+  const [Q, R] = nd.la[fn](NDA(shape, a));
+  record(name, {op: fn, seed, shape, family: fam}, {Q: [Q.data, Array.from(Q.shape)], R: [R.data, Array.from(R.shape)]});
+}
+function caseLU(name, seed, shape, fam = 'dense') {
+  const N = shape[shape.length - 1], n = shape.reduce((a, b) => a * b, 1);
+  const a = fill(seed, n);
+  for (let o = 0, b = 0; o < n; o += N * N, b++) applyFamily(fam, a.subarray(o, o + N * N), N, N, seed + b);
+  const [LU, P] = nd.la.lu_decomp(NDA(shape, a));
+  record(name, {op: 'lu_decomp', seed, shape, family: fam}, {LU: [LU.data, Array.from(LU.shape)], P: [P.data, Array.from(P.shape)]});
+}
+function caseSVD(name, seed, shape, fam = 'dense', fn = 'svd_decomp') {
+  const M = shape[shape.length - 2], N = shape[shape.length - 1], n = shape.reduce((a, b) => a * b, 1);
+  const a = fill(seed, n);
+  for (let o = 0, b = 0; o < n; o += M * N, b++) applyFamily(fam, a.subarray(o, o + M * N), M, N, seed + b);
+  const [U, sv, V] = nd.la[fn](NDA(shape, a));
+  record(name, {op: fn, seed, shape, family: fam},
+    {U: [U.data, Array.from(U.shape)], sv: [sv.data, Array.from(sv.shape)], V: [V.data, Array.from(V.shape)]});
+}
+function sample(typed, n, seed) {
+  const idx = new Int32Array(n), val = new Float64Array(n);
+  for (let i = 0; i < n; i++) { idx[i] = hashIdx(seed, i, typed.length); val[i] = typed[idx[i]]; }
+  return [idx, val];
+}
+
+const what = process.argv[2] || 'small';
+const t0 = Date.now();
+
+if (what === 'small') {
+  /* generator self-check vectors */
+  record('rng', {op: 'rng', seed: 12345, n: 64, offset: 1000}, {u: [fill(12345, 64, 1000), [64]]});
+  /* C1: 64^2 matmul + 32^2 QR (BASELINE.json configs[0]) and 32^2 of the other ops */
+  caseMatmul('c1_matmul64', 1, 2, [64, 64], [64, 64]);
+  caseQR('c1_qr32', 3, [32, 32]);
+  caseQR('c1_qrfull32', 3, [32, 32], 'dense', 'qr_decomp_full');
+  caseLU('c1_lu32', 4, [32, 32]);
+  caseSVD('c1_svd32', 8, [32, 32]);
+  caseSVD('c1_svdjac32', 8, [32, 32], 'dense', 'svd_jac_2sided');
+  /* mid sizes, deliberately not tile multiples */
+  caseMatmul('mid_matmul', 11, 12, [96, 80], [80, 112]);
+  caseMatmul('mid_matmul_sq200', 13, 14, [200, 200], [200, 200]);
+  caseQR('mid_qr96', 15, [96, 96]);
+  caseQR('mid_qr_wide', 16, [40, 72]);
+  caseQR('mid_qr_tall', 17, [72, 40]);
+  caseQR('mid_qrfull_tall', 17, [24, 10], 'dense', 'qr_decomp_full');
+  caseQR('mid_qr130', 18, [130, 130]);
+  caseLU('mid_lu96', 19, [96, 96]);
+  caseLU('mid_lu130', 20, [130, 130]);
+  caseSVD('mid_svd96', 21, [96, 96]);
+  caseSVD('mid_svdjac48', 22, [48, 48], 'dense', 'svd_jac_2sided');
+  caseSVD('mid_svd_wide', 23, [24, 40]);
+  caseSVD('mid_svd_tall', 24, [40, 24]);
+  /* batched + broadcast matmul shapes (matmul_test.js:86-118 style) */
+  caseMatmul('bc_matmul_a', 31, 32, [3, 1, 5, 7], [4, 7, 6]);
+  caseMatmul('bc_matmul_b', 33, 34, [2, 3, 4, 5], [5, 2]);
+  caseMatmul('bc_matmul_c', 35, 36, [6, 9], [2, 1, 3, 9, 4]);
+  caseMatmul('bc_matmul_vec', 37, 38, [1, 13], [13, 1]);
+  caseMatmul('bc_matmul_batch', 39, 40, [5, 33, 17], [5, 17, 29]);
+  /* batched decompositions */
+  caseQR('b_qr', 41, [3, 2, 12, 12]);
+  caseLU('b_lu', 42, [4, 17, 17]);
+  caseSVD('b_svd', 43, [3, 20, 20]);
+  /* edge families (qr_test.js:67-146, lu_test.js:82-94, _generic_test_svd_decomp.js:180-336) */
+  for (const fam of ['sparse10', 'zerorow', 'zerocol', 'rankdef', 'diag', 'triu']) {
+    caseQR('edge_qr_' + fam, 50, [2, 16, 16], fam);
+    caseSVD('edge_svdjac_' + fam, 52, [2, 16, 16], fam, 'svd_jac_2sided');
+  }
+  for (const fam of ['sparse10', 'diag', 'triu']) caseLU('edge_lu_' + fam, 51, [2, 16, 16], fam);
+  for (const fam of ['sparse10', 'diag']) caseSVD('edge_svd_' + fam, 52, [2, 16, 16], fam);
+  caseQR('edge_qr_1x1', 53, [1, 1]); caseLU('edge_lu_1x1', 54, [1, 1]); caseSVD('edge_svd_1x1', 55, [3, 1, 1]);
+  caseMatmul('edge_matmul_1x1', 56, 57, [1, 1], [1, 1]);
+}
+
+if (what === 'c2') {
+  const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
+  const t = Date.now();
+  const C = nd.la.matmul2(NDA([N, N], A), NDA([N, N], B)).data;
+  const secs = (Date.now() - t) / 1e3;
+  const [idx, val] = sample(C, 4096, 605);
+  const rows = new Int32Array(64), rowsum = new Float64Array(64);
+  for (let r = 0; r < 64; r++) { rows[r] = hashIdx(606, r, N); let s = 0; for (let j = 0; j < N; j++) s += C[rows[r] * N + j]; rowsum[r] = s; }
+  record('c2_matmul4096', {op: 'matmul2', seedA: 5, seedB: 6, shapeA: [N, N], shapeB: [N, N], fro: fro(C), ref_seconds: secs},
+    {idx: [idx, [4096]], val: [val, [4096]], rows: [rows, [64]], rowsum: [rowsum, [64]]});
+}
+
+if (what === 'c3') {
+  const N = 2048, a = fill(7, N * N);
+  let t = Date.now();
+  const [Q, R] = nd.la.qr_decomp(NDA([N, N], a)); const tqr = (Date.now() - t) / 1e3;
+  t = Date.now();
+  const [LU, P] = nd.la.lu_decomp(NDA([N, N], a)); const tlu = (Date.now() - t) / 1e3;
+  const dR = new Float64Array(N); for (let i = 0; i < N; i++) dR[i] = R.data[i * N + i];
+  const [qi, qv] = sample(Q.data, 4096, 701), [ri, rv] = sample(R.data, 4096, 702), [li, lv] = sample(LU.data, 4096, 703);
+  record('c3_qr2048', {op: 'qr_decomp', seed: 7, shape: [N, N], froQ: fro(Q.data), froR: fro(R.data), ref_seconds: tqr},
+    {diagR: [dR, [N]], Qidx: [qi, [4096]], Qval: [qv, [4096]], Ridx: [ri, [4096]], Rval: [rv, [4096]]});
+  record('c3_lu2048', {op: 'lu_decomp', seed: 7, shape: [N, N], froLU: fro(LU.data), ref_seconds: tlu},
+    {P: [P.data, [N]], LUidx: [li, [4096]], LUval: [lv, [4096]]});
+}
+
+if (what === 'c4') {
+  const N = 2048, a = fill(9, N * N);
+  const t = Date.now();
+  const [U, sv, V] = nd.la.svd_decomp(NDA([N, N], a)); const secs = (Date.now() - t) / 1e3;
+  const [ui, uv] = sample(U.data, 4096, 901), [vi, vv] = sample(V.data, 4096, 902);
+  record('c4_svd2048', {op: 'svd_decomp', seed: 9, shape: [N, N], ref_seconds: secs},
+    {sv: [sv.data, [N]], Uidx: [ui, [4096]], Uval: [uv, [4096]], Vidx: [vi, [4096]], Vval: [vv, [4096]]});
+}
+
+if (what === 'c5') {
+  const N = 512, stride = parseInt(process.argv[3] || '16'), B = 1024, members = [];
+  for (let b = 0; b < B; b += stride) members.push(b);
+  const svs = new Float64Array(members.length * N); let secs = 0;
+  members.forEach((b, k) => {
+    const a = fill(1000 + b, N * N); const t = Date.now();
+    const sv = nd.la.svd_decomp(NDA([N, N], a))[1].data; secs += (Date.now() - t) / 1e3;
+    svs.set(sv, k * N);
+    if (k % 8 === 0) console.log('c5 member', b);
+  });
+  record('c5_svd512', {op: 'svd_decomp', seed_base: 1000, batch: B, stride, shape: [N, N], ref_seconds_per_matrix: secs / members.length},
+    {members: [Int32Array.from(members), [members.length]], sv: [svs, [members.length, N]]});
+}
+console.log('done', what, ((Date.now() - t0) / 1e3).toFixed(1) + ' s');

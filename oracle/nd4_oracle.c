@@ -1,0 +1,297 @@
+/* nd4_oracle.c — see nd4_oracle.h.   *** TEST INFRASTRUCTURE, NOT PRODUCT CODE ***
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile).
+ * Parity pinned against tests/golden (reference-generated) by tests/test_oracle_golden.py.
+ */
+#include "nd4_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ generator */
+static inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+double nd4o_uniform(uint32_t seed, uint32_t idx) {
+  uint32_t hi = fmix32(idx ^ fmix32(seed));
+  uint32_t lo = fmix32(hi + 0x9E3779B9u + idx);
+  double m = (double)(hi >> 5) * 67108864.0 + (double)(lo >> 6);
+  return m * 0x1p-52 - 1.0;
+}
+void nd4o_fill_uniform(uint32_t seed, uint32_t offset, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; i++) out[i] = nd4o_uniform(seed, offset + (uint32_t)i);
+}
+
+/* ------------------------------------------------------------------ matmul
+ * matmul.js:49-53: for i: for k: for j: C[i,j] += A[i,k]*B[k,j]  (C zero-initialised, k ascending) */
+static void matmul_ikj(int64_t I, int64_t K, int64_t J, const double* A, const double* B, double* C) {
+  for (int64_t i = 0; i < I; i++) {
+    double* c = C + i * J;
+    for (int64_t j = 0; j < J; j++) c[j] = 0.0;
+    for (int64_t k = 0; k < K; k++) {
+      const double a = A[i * K + k];
+      const double* b = B + k * J;
+      for (int64_t j = 0; j < J; j++) c[j] += a * b[j];
+    }
+  }
+}
+void nd4o_matmul_batched(int64_t batch, int64_t I, int64_t K, int64_t J,
+                         const double* A, int64_t sA, const double* B, int64_t sB, double* C) {
+  for (int64_t b = 0; b < batch; b++) matmul_ikj(I, K, J, A + b * sA, B + b * sB, C + b * I * J);
+}
+int nd4o_matmul2(int ndimA, const int32_t* shA, const double* A,
+                 int ndimB, const int32_t* shB, const double* B, int32_t* shC, double* C) {
+  const int64_t I = shA[ndimA - 2], K = shA[ndimA - 1], J = shB[ndimB - 1];
+  if (shB[ndimB - 2] != K) return -1;                          /* matmul.js:101-102 */
+  const int nd = ndimA > ndimB ? ndimA : ndimB, nb = nd - 2;
+  int32_t shape[32]; int64_t strA[32], strB[32];
+  if (nd > 32) return -3;
+  for (int d = 0; d < nb; d++) shape[d] = 1;
+  /* matmul.js:110-116 common (broadcast) shape */
+  for (int w = 0; w < 2; w++) {
+    const int nda = w ? ndimB : ndimA; const int32_t* sh = w ? shB : shA;
+    for (int i = nb, j = nda - 2; i-- > 0 && j-- > 0;) {
+      if (shape[i] == 1) shape[i] = sh[j];
+      else if (shape[i] != sh[j] && sh[j] != 1) return -2;
+    }
+  }
+  /* element strides of the leading axes, 0 where the operand broadcasts */
+  for (int w = 0; w < 2; w++) {
+    const int nda = w ? ndimB : ndimA; const int32_t* sh = w ? shB : shA; int64_t* st = w ? strB : strA;
+    int64_t s = w ? K * J : I * K;
+    for (int i = nb - 1; i >= 0; i--) {
+      const int j = i - nd + nda;
+      if (j < 0) { st[i] = 0; continue; }
+      st[i] = sh[j] > 1 ? s : 0; s *= sh[j];
+    }
+  }
+  int64_t batch = 1; for (int d = 0; d < nb; d++) batch *= shape[d];
+  int32_t idx[32] = {0};
+  for (int64_t b = 0; b < batch; b++) {
+    int64_t a = 0, bb = 0;
+    for (int d = 0; d < nb; d++) { a += idx[d] * strA[d]; bb += idx[d] * strB[d]; }
+    matmul_ikj(I, K, J, A + a, B + bb, C + b * I * J);
+    for (int d = nb - 1; d >= 0; d--) { if (++idx[d] < shape[d]) break; idx[d] = 0; }
+  }
+  if (shC) { for (int d = 0; d < nb; d++) shC[d] = shape[d]; shC[nb] = (int32_t)I; shC[nb + 1] = (int32_t)J; }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ Givens helpers */
+/* _giv_rot.js:22-37 */
+void nd4o_giv_rot_qr(double a, double b, double* c, double* s, double* norm) {
+  const double fa = fabs(a), fb = fabs(b);
+  const double mx = fa > fb ? fa : fb;        /* Math.max; NaN falls through to the 0===max test as in JS? (NaN!==0) */
+  if (0.0 == mx) { *c = 1; *s = 0; *norm = 0; return; }
+  a /= mx; b /= mx;
+  double n = sqrt(a * a + b * b);
+  a /= n; b /= n; n *= mx;
+  *c = a; *s = b; *norm = n;
+}
+/* _giv_rot.js:42-67: W_i' = c*W_i + s*W_j ; W_j' = c*W_j - s*W_i over n contiguous elements */
+static inline void giv_rot_rows(double* W, int64_t n, int64_t i, int64_t j, double c, double s) {
+  for (int64_t k = 0; k < n; k++) {
+    const double wi = W[i + k], wj = W[j + k];
+    W[i + k] = c * wi + s * wj;
+    W[j + k] = c * wj - s * wi;
+  }
+}
+/* _giv_rot.js:72-87: column rotation on an N x N matrix: W_i' = c*W_i - s*W_j ; W_j' = c*W_j + s*W_i */
+static inline void giv_rot_cols(double* W, int64_t N, int64_t i, int64_t j, double c, double s) {
+  for (int64_t k = 0; k < N; k++, i += N, j += N) {
+    const double wi = W[i], wj = W[j];
+    W[i] = c * wi - s * wj;
+    W[j] = c * wj + s * wi;
+  }
+}
+/* transpose_inplace.js:21-30 */
+static void transpose_inplace(int64_t N, double* A) {
+  for (int64_t i = 0; i < N - 1; i++)
+    for (int64_t j = i + 1; j < N; j++) { double t = A[N * i + j]; A[N * i + j] = A[N * j + i]; A[N * j + i] = t; }
+}
+
+/* ------------------------------------------------------------------ QR */
+void nd4o_qr_decomp_full(int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  const int64_t B = 8;                                           /* qr.js:33 (64/8 for float64) */
+  memcpy(R, A, sizeof(double) * batch * M * N);                  /* qr.js:37 */
+  memset(Q, 0, sizeof(double) * batch * M * M);
+  for (int64_t b = 0; b < batch; b++) {
+    double* q = Q + b * M * M; double* r = R + b * M * N;
+    for (int64_t i = 0; i < M; i++) q[M * i + i] = 1.0;          /* qr.js:52 */
+    for (int64_t J = 0; J < N; J += B)                           /* qr.js:54-57 blocked order */
+      for (int64_t I = J; I < M; I += B)
+        for (int64_t i = I; i < I + B && i < M; i++)
+          for (int64_t j = J; j < J + B && j < N && j < i; j++) {
+            const int64_t ij = N * i + j, jj = N * j + j;
+            const double R_ij = r[ij]; if (0.0 == R_ij) continue;            /* :60 */
+            double c, s, norm; nd4o_giv_rot_qr(r[jj], R_ij, &c, &s, &norm);  /* :61-62 */
+            r[ij] = 0.0; if (0.0 == s) continue;                             /* :63 */
+            r[jj] = norm;                                                    /* :64 */
+            giv_rot_rows(r, N - 1 - j, jj + 1, ij + 1, c, s);                /* :65-66 */
+            giv_rot_rows(q, 1 + i, M * j, M * i, c, s);                      /* :67-68 */
+          }
+    transpose_inplace(M, q);                                     /* qr.js:70 */
+  }
+}
+
+void nd4o_qr_decomp(int64_t batch, int64_t Nr, int64_t Mc, const double* A, double* Q, double* R) {
+  /* reference naming (qr.js:88): [N,M] = rows, cols */
+  const int64_t N = Nr, M = Mc;
+  if (N <= M) { nd4o_qr_decomp_full(batch, N, M, A, Q, R); return; }        /* qr.js:91 */
+  memcpy(Q, A, sizeof(double) * batch * N * M);                              /* qr.js:93 */
+  memset(R, 0, sizeof(double) * batch * M * M);
+  for (int64_t b = 0; b < batch; b++) {
+    double* q = Q + b * N * M; double* r = R + b * M * M;
+    for (int64_t i = 1; i < N; i++) {                                        /* qr.js:104-120 */
+      const int64_t I = i < M ? i : M;
+      for (int64_t j = 0; j < I; j++) {
+        const int64_t ij = M * i + j, jj = M * j + j;
+        const double R_ij = q[ij]; if (0.0 == R_ij) continue;
+        double c, s, norm; nd4o_giv_rot_qr(q[jj], R_ij, &c, &s, &norm);
+        if (s != 0.0) {
+          if (c < 0) { c *= -1; s *= -1; norm *= -1; }                       /* :111-115 */
+          giv_rot_rows(q, M - 1 - j, jj + 1, ij + 1, c, s);
+          q[jj] = norm;
+        }
+        q[ij] = s;
+      }
+    }
+    for (int64_t i = 0; i < M; i++)                                          /* qr.js:123-127 */
+      for (int64_t j = i; j < M; j++) { r[M * i + j] = q[M * i + j]; q[M * i + j] = (i == j) ? 1.0 : 0.0; }
+    for (int64_t i = N; --i > 0;) {                                          /* qr.js:130-138 */
+      const int64_t I = i < M ? i : M;
+      for (int64_t j = I; j-- > 0;) {
+        const double s = q[M * i + j]; if (0.0 == s) continue;
+        q[M * i + j] = 0.0;
+        const double c = sqrt((1 - s) * (1 + s));
+        giv_rot_rows(q, M - j, M * i + j, M * j + j, c, s);
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ LU (lu.js:24-81) */
+void nd4o_lu_decomp(int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
+  memcpy(LU, A, sizeof(double) * batch * N * N);
+  for (int64_t b = 0; b < batch; b++) {
+    double* lu = LU + b * N * N; int32_t* p = P + b * N;
+    for (int64_t i = 0; i < N; i++) p[i] = (int32_t)i;
+    for (int64_t i = 0; i < N; i++) {
+      double* row_i = lu + i * N;
+      int64_t piv = i;                                                       /* :48-52 first strict max */
+      for (int64_t j = i + 1; j < N; j++)
+        if (fabs(lu[N * j + i]) > fabs(lu[N * piv + i])) piv = j;
+      if (i != piv) {                                                        /* :54-62 */
+        int32_t t = p[i]; p[i] = p[piv]; p[piv] = t;
+        double* row_p = lu + piv * N;
+        for (int64_t j = 0; j < N; j++) { double tmp = row_i[j]; row_i[j] = row_p[j]; row_p[j] = tmp; }
+      }
+      for (int64_t j = i + 1; j < N; j++) {                                  /* :65-73 */
+        double* row_j = lu + j * N;
+        const double scale = row_j[i] / row_i[i];
+        row_j[i] = scale;
+        for (int64_t k = i + 1; k < N; k++) row_j[k] -= scale * row_i[k];
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ two-sided Jacobi SVD */
+/* _svd_jac_utils.js:72-114 */
+static void svd_jac_angles(double S_pp, double S_pq, double S_qp, double S_qq,
+                           double* pca, double* psa, double* pcb, double* psb) {
+  double x = atan2(S_qp - S_pq, S_qq + S_pp),
+         y = atan2(S_qp + S_pq, S_qq - S_pp);
+  const double a = (x - y) / 2, b = (x + y) / 2;
+  double ca = cos(a), sa = sin(a), cb = cos(b), sb = sin(b);
+  x = cb * (sa * S_qp + ca * S_pp) - sb * (sa * S_qq + ca * S_pq);
+  y = sb * (ca * S_qp - sa * S_pp) + cb * (ca * S_qq - sa * S_pq);
+  if (fabs(x) < fabs(y)) {
+    double t = sa; sa = ca; ca = -t;            /* [sa,ca] = [ca,-sa] */
+    t = cb; cb = sb; sb = -t;                   /* [cb,sb] = [sb,-cb] */
+    x = y;
+  }
+  if (x < 0) { cb = -cb; sb = -sb; }
+  *pca = ca; *psa = sa; *pcb = cb; *psb = sb;
+}
+
+/* stable merge sort of indices by descending key (ties keep ascending index; the reference's
+ * Int32Array.sort((i,j)=>sv[j]-sv[i]) leaves tie order to the engine, _svd_jac_utils.js:158) */
+static void sort_desc(int64_t n, const double* key, int32_t* ord, int32_t* tmp) {
+  for (int64_t w = 1; w < n; w *= 2) {
+    for (int64_t lo = 0; lo < n; lo += 2 * w) {
+      int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, i = lo, j = mid, k = lo;
+      while (i < mid && j < hi) tmp[k++] = (key[ord[j]] > key[ord[i]]) ? ord[j++] : ord[i++];
+      while (i < mid) tmp[k++] = ord[i++];
+      while (j < hi) tmp[k++] = ord[j++];
+    }
+    memcpy(ord, tmp, sizeof(int32_t) * n);
+  }
+}
+
+/* _svd_jac_utils.js:123-188 */
+static void svd_jac_post(int64_t N, double* U, const double* S, double* V, double* sv, int32_t* ord, int32_t* tmp) {
+  for (int64_t i = 0; i < N; i++) sv[i] = S[N * i + i];                      /* 1) */
+  for (int64_t i = N; i-- > 0;) {                                            /* 2) make positive */
+    const double s = sv[i];
+    if (s < 0 || (s == 0 && signbit(s))) {
+      sv[i] = -s;
+      for (int64_t j = 0; j < N; j++) U[N * i + j] *= -1;
+    }
+  }
+  for (int64_t i = 0; i < N; i++) ord[i] = (int32_t)i;                       /* 3) sort */
+  sort_desc(N, sv, ord, tmp);
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = i;;) {
+      int64_t t = ord[j]; ord[j] = (int32_t)j; j = t;
+      if (j <= i) break;
+      double* uI = U + (int64_t)ord[j] * N; double* uJ = U + j * N;
+      double* vI = V + (int64_t)ord[j] * N; double* vJ = V + j * N;
+      for (int64_t k = 0; k < N; k++) { double x = uI[k]; uI[k] = uJ[k]; uJ[k] = x; }
+      for (int64_t k = 0; k < N; k++) { double x = vI[k]; vI[k] = vJ[k]; vJ[k] = x; }
+      double x = sv[ord[j]]; sv[ord[j]] = sv[j]; sv[j] = x;
+    }
+  transpose_inplace(N, U);                                                   /* 4) */
+}
+
+int nd4o_svd_jac_2sided(int64_t batch, int64_t N, const double* A, double* U, double* sv, double* V) {
+  if (N == 1) {                                                              /* svd_jac_2sided.js:66-78 */
+    for (int64_t i = 0; i < batch; i++) {
+      const double a = A[i];
+      if (a < 0.0) { sv[i] = -a; U[i] = -1.0; } else { sv[i] = a; U[i] = 1.0; }
+      V[i] = 1.0;
+    }
+    return 0;
+  }
+  const double eps = 0x1p-52, TOL = (N * eps) * (N * eps);                   /* :57 */
+  const int64_t B = 8;
+  double* S = (double*)malloc(sizeof(double) * N * N);
+  int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * 2 * N);
+  int sweeps_max = 0;
+  for (int64_t b = 0; b < batch; b++) {
+    double* u = U + b * N * N; double* v = V + b * N * N;
+    memcpy(S, A + b * N * N, sizeof(double) * N * N);
+    for (int64_t i = 0; i < N; i++) for (int64_t j = 0; j < N; j++) u[N * i + j] = v[N * i + j] = (i == j);
+    int sweeps = 0;
+    for (int finished = 0; !finished;) {                                     /* :95-134 */
+      finished = 1; sweeps++;
+      for (int64_t Q = 0; Q < N; Q += B)
+        for (int64_t P = 0; P <= Q; P += B)
+          for (int64_t q = Q; q < Q + B && q < N; q++)
+            for (int64_t p = P; p < P + B && p < q; p++) {
+              const double S_pp = S[N * p + p], S_pq = S[N * p + q], S_qp = S[N * q + p], S_qq = S[N * q + q];
+              if (!(S_pq * S_pq + S_qp * S_qp > fabs(S_pp * S_qq) * TOL)) continue;   /* :112 */
+              finished = 0;
+              double ca, sa, cb, sb; svd_jac_angles(S_pp, S_pq, S_qp, S_qq, &ca, &sa, &cb, &sb);
+              giv_rot_rows(S, N, N * p, N * q, ca, sa);
+              giv_rot_cols(S, N, p, q, cb, sb);
+              S[N * p + q] = S[N * q + p] = 0.0;
+              giv_rot_rows(u, N, N * p, N * q, ca, sa);
+              giv_rot_rows(v, N, N * p, N * q, cb, -sb);
+            }
+    }
+    if (sweeps > sweeps_max) sweeps_max = sweeps;
+    svd_jac_post(N, u, S, v, sv + b * N, ord, ord + N);
+  }
+  free(S); free(ord);
+  return sweeps_max;
+}

@@ -1,0 +1,54 @@
+/* nd4_oracle — CPU restatement of the nd4js `nd.la` hot path.   *** TEST INFRASTRUCTURE ***
+ *
+ * This library is the parity CHECKER and the `cpu_baseline` ("port") of bench.py. It is never
+ * linked, imported or called by the product path (libnd4hip.so, package nd4js_amd): only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Every function restates one reference function (file:line relative to /root/reference/),
+ * keeping its exact floating-point operation order (plain IEEE fp64, no FMA: build with
+ * -ffp-contract=off), so that matmul / LU / Givens-QR are bit-identical to the JS reference.
+ * Parity is PINNED: tests/test_oracle_golden.py checks it against tests/golden (.npy files), which were
+ * produced by the real reference bundle (oracle/gen_golden.js).
+ */
+#ifndef ND4_ORACLE_H
+#define ND4_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* counter-based input generator shared by every language in this repo (not reference code) */
+double nd4o_uniform(uint32_t seed, uint32_t idx);
+void   nd4o_fill_uniform(uint32_t seed, uint32_t offset, int64_t n, double* out);
+
+/* src/la/matmul.js:31-74 (matmul2_RR hot loop :49-53) with the broadcast odometer :44-70.
+ * shapes are full NDArray shapes (ndim >= 2); C must hold prod(broadcast shape). Returns 0, or
+ * -1 inner-dim mismatch, -2 not broadcast-compatible (matmul.js:95-116). shapeC (size
+ * max(ndimA,ndimB)) is written when non-NULL. */
+int nd4o_matmul2(int ndimA, const int32_t* shapeA, const double* A,
+                 int ndimB, const int32_t* shapeB, const double* B,
+                 int32_t* shapeC, double* C);
+/* flat batched form: C[b] = A[b*strideA] * B[b*strideB]  (stride 0 = broadcast), i-k-j order */
+void nd4o_matmul_batched(int64_t batch, int64_t I, int64_t K, int64_t J,
+                         const double* A, int64_t strideA, const double* B, int64_t strideB, double* C);
+
+/* src/la/_giv_rot.js:22-37 */
+void nd4o_giv_rot_qr(double a, double b, double* c, double* s, double* norm);
+
+/* src/la/qr.js:27-77  qr_decomp_full: A[batch,M,N] -> Q[batch,M,M], R[batch,M,N] */
+void nd4o_qr_decomp_full(int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+/* src/la/qr.js:80-145 qr_decomp (economic): Q[batch,M,min(M,N)], R[batch,min(M,N),N] */
+void nd4o_qr_decomp(int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+
+/* src/la/lu.js:24-81  LU[batch,N,N], P[batch,N] (permutation vector: A[P[i],:] = (L*U)[i,:]) */
+void nd4o_lu_decomp(int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+
+/* src/la/svd_jac_2sided.js:30-144 (square input only; the rectangular pre-reduction :42-52 is
+ * host-side composition) + _svd_jac_utils.js:72-114 (angles), :123-188 (post-processing).
+ * U[batch,N,N], sv[batch,N], V[batch,N,N] (rows of V = right singular vectors). Returns sweeps. */
+int nd4o_svd_jac_2sided(int64_t batch, int64_t N, const double* A, double* U, double* sv, double* V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,41 @@
+"""Input families of the golden fixtures — numpy twin of oracle/gen_golden.js `applyFamily`.
+
+They mirror the reference tests' own input families (qr_test.js:67-146, lu_test.js:82-94,
+_generic_test_svd_decomp.js:180-336): dense, ~10 % zeros, zero row / column, rank deficient,
+diagonal, upper triangular."""
+import numpy as np
+
+from nd4js_amd.rng import fill_uniform, hash_idx
+
+
+def apply_family(fam, a, seed):
+    M, N = a.shape
+    flat = a.reshape(-1)
+    if fam == "dense":
+        pass
+    elif fam == "sparse10":
+        z = hash_idx(seed + 77, np.arange(flat.size), 10) == 0
+        flat[z] = 0.0
+    elif fam == "zerorow":
+        a[int(hash_idx(seed + 78, 0, M)), :] = 0.0
+    elif fam == "zerocol":
+        a[:, int(hash_idx(seed + 79, 0, N))] = 0.0
+    elif fam == "rankdef":
+        rank = max(1, min(M, N) >> 1)
+        for i in range(rank, M):
+            a[i, :] = 0.5 * a[(i - rank) % rank, :] - 0.25 * a[(i + 1) % rank, :]
+    elif fam == "diag":
+        a[...] = np.where(np.eye(M, N, dtype=bool), a, 0.0)
+    elif fam == "triu":
+        a[...] = np.triu(a)
+    else:
+        raise ValueError(fam)
+    return a
+
+
+def make_input(seed, shape, family="dense"):
+    shape = tuple(shape)
+    a = fill_uniform(seed, int(np.prod(shape))).reshape((-1,) + shape[-2:])
+    for b in range(a.shape[0]):
+        apply_family(family, a[b], seed + b)
+    return a.reshape(shape)
