@@ -1,0 +1,105 @@
+/* nd4hip.h — C ABI of libnd4hip.so: the MI355X (gfx950) backend of nd4js's `nd.la` hot path.
+ *
+ * The reference (nd4js v1.3.0, pure JavaScript) has no FFI/plugin layer; its boundary for this path
+ * is the JS call contract of src/la/{matmul,qr,lu,svd}.js on dense row-major Float64Array /
+ * Int32Array buffers. This header is the C ABI a maintainer binds underneath those
+ * functions (N-API shim: nd4js_amd/csrc/napi_shim.c; ctypes: nd4js_amd/_lib.py).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every matrix is dense, row-major, contiguous, fp64; leading
+ *    (batch) dimensions are flattened by the host into `batch`;
+ *  - inputs are never modified; outputs are caller-allocated;
+ *  - return 0 on success, negative on error; nd4hip_last_error() gives the message (thread-local);
+ *  - `*_dev` entry points take DEVICE pointers and enqueue on the handle's stream without
+ *    synchronising the host (except where a host-visible scalar is returned: noted per function);
+ *    the un-suffixed entry points take HOST pointers (what the JS TypedArrays are) and do
+ *    H2D -> kernels -> D2H -> stream sync internally;
+ *  - one handle = one GPU + one stream + one growable device workspace; calls on one handle are
+ *    serialised by the caller (the JS host is single-threaded, like the reference).
+ */
+#ifndef ND4HIP_H
+#define ND4HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nd4hip_handle nd4hip_handle;
+
+#define ND4HIP_OK            0
+#define ND4HIP_ERR_ARG      -1   /* bad argument / shape */
+#define ND4HIP_ERR_HIP      -2   /* HIP runtime error (message has the hipError string) */
+#define ND4HIP_ERR_NOCONV   -3   /* Jacobi SVD hit the sweep limit */
+#define ND4HIP_ERR_NODEV    -4   /* no usable GPU */
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+int  nd4hip_device_count(void);
+/* device < 0: use the current HIP device. Creates a private non-blocking stream. */
+int  nd4hip_create(nd4hip_handle** out, int device);
+void nd4hip_destroy(nd4hip_handle* h);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
+ * the private stream. */
+int  nd4hip_set_stream(nd4hip_handle* h, void* hip_stream);
+int  nd4hip_synchronize(nd4hip_handle* h);
+const char* nd4hip_last_error(void);
+const char* nd4hip_version(void);
+
+/* device memory for hosts without their own allocator (the N-API shim, C/C++ drivers) */
+int  nd4hip_malloc(nd4hip_handle* h, size_t bytes, void** dev_ptr);
+int  nd4hip_free(nd4hip_handle* h, void* dev_ptr);
+int  nd4hip_memcpy_h2d(nd4hip_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int  nd4hip_memcpy_d2h(nd4hip_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+
+/* hipEvent timing on the handle's stream (bench.py roofline leg): start, enqueue work, stop -> ms */
+int  nd4hip_timer_start(nd4hip_handle* h);
+int  nd4hip_timer_stop(nd4hip_handle* h, float* ms_out);   /* synchronises the stream */
+
+/* synthetic inputs: out[i] = u(seed, offset+i) in [-1,1), bit-identical to nd4js_amd/rng.py */
+int  nd4hip_fill_uniform_dev(nd4hip_handle* h, uint32_t seed, uint32_t offset, int64_t n, double* out_dev);
+
+/* ---- matmul2: replaces the matmul2_RR hot loop, src/la/matmul.js:31-74 (:49-53) -------------
+ * C[b] (I x J) = A[b] (I x K) * B[b] (K x J), b = 0..batch-1; element strides strideA/strideB
+ * between consecutive batch members, 0 = the operand is broadcast (the reference's odometer,
+ * matmul.js:44-70, is flattened into (batch, stride) groups by the host wrapper). C is dense
+ * [batch, I, J]. */
+int nd4hip_dgemm_batched_dev(nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
+                             const double* A, int64_t strideA, const double* B, int64_t strideB, double* C);
+int nd4hip_dgemm_batched    (nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
+                             const double* A, int64_t strideA, const double* B, int64_t strideB, double* C);
+
+/* general strided form used by the decompositions and exposed for tests:
+ * C = alpha * op(A) * op(B) + beta * C, row-major with leading dimensions; transA/transB != 0
+ * means the stored matrix is the transpose of the operand (A stored K x M, B stored N x K). */
+int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                        double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                        double beta, double* C, int64_t ldc);
+
+/* ---- lu_decomp: replaces src/la/lu.js:24-81 ---------------------------------------------------
+ * A [batch,N,N] -> LU [batch,N,N] (unit-L below the diagonal, U on/above) and the PERMUTATION
+ * VECTOR P [batch,N] int32 with A[P[i],:] = (L*U)[i,:] (not LAPACK ipiv); pivot = first maximum of
+ * |x| down the column (lu.js:48-52). */
+int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+int nd4hip_dgetrf_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+
+/* ---- qr_decomp: replaces src/la/qr.js:80-145 / qr_decomp_full :27-77 ----------------------------
+ * A [batch,M,N] -> Q [batch,M,L], R [batch,L,N], L = min(M,N); blocked Householder with the
+ * reference's Givens sign convention restored (R_jj >= 0 wherever a column had something to
+ * eliminate, det(Q)=+1 for M <= N: SURVEY.md §8 A4). */
+int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4hip_dgeqrf_q_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+
+/* ---- svd_decomp: replaces the output contract of src/la/svd.js:25 (= svd_dc.js:883-932) ----------
+ * A [batch,M,N] -> U [batch,M,L], sv [batch,L] (>= 0, descending), V [batch,L,N] (rows = right
+ * singular vectors), L = min(M,N); one-sided Jacobi with the reference's Jacobi post-processing
+ * contract (_svd_jac_utils.js:123-188). sweeps_out / offnorm_out are HOST pointers (may be NULL):
+ * max sweeps over the batch and the largest remaining |a_p.a_q| / (|a_p||a_q|). Both forms
+ * synchronise the stream (the sweep loop is host-driven). */
+int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
+                               double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
+int nd4hip_dgesvdj_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
+                               double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ND4HIP_H */

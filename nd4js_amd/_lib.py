@@ -1,0 +1,130 @@
+"""ctypes loader for libnd4hip.so (the C ABI of include/nd4hip.h).
+
+There is NO CPU fallback: if the HIP library is missing, fails to load, or no GPU is usable, every
+entry point raises. `load()` only dlopens the library (works without a GPU, used by the CPU test
+that checks the exported symbols); `handle()` needs a real device.
+"""
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnd4hip.so")
+
+c_dp = ctypes.c_void_p   # device or host pointer to double
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol include/nd4hip.h declares
+SIGNATURES = {
+    "nd4hip_device_count": (c_int, []),
+    "nd4hip_create": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int]),
+    "nd4hip_destroy": (None, [ctypes.c_void_p]),
+    "nd4hip_set_stream": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nd4hip_synchronize": (c_int, [ctypes.c_void_p]),
+    "nd4hip_last_error": (ctypes.c_char_p, []),
+    "nd4hip_version": (ctypes.c_char_p, []),
+    "nd4hip_malloc": (c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "nd4hip_free": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nd4hip_memcpy_h2d": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "nd4hip_memcpy_d2h": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "nd4hip_timer_start": (c_int, [ctypes.c_void_p]),
+    "nd4hip_timer_stop": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "nd4hip_fill_uniform_dev": (c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, c_i64, c_dp]),
+    "nd4hip_dgemm_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
+    "nd4hip_dgemm_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
+    "nd4hip_dgemm_ex_dev": (c_int, [ctypes.c_void_p, c_int, c_int, c_i64, c_i64, c_i64, ctypes.c_double, c_dp, c_i64,
+                                    c_dp, c_i64, ctypes.c_double, c_dp, c_i64]),
+    "nd4hip_dgetrf_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, ctypes.c_void_p]),
+    "nd4hip_dgetrf_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, ctypes.c_void_p]),
+    "nd4hip_dgeqrf_q_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_dgeqrf_q_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_dgesvdj_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
+                                           ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
+    "nd4hip_dgesvdj_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
+                                       ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+class Nd4HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nd4hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen libnd4hip.so and bind every symbol. Raises if the library is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError("%s not built: run `python -m nd4js_amd.build` (hipcc, gfx950). "
+                                  "There is no CPU fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Nd4HipError(rc, load().nd4hip_last_error().decode("utf-8", "replace"))
+
+
+class Handle:
+    """One GPU + stream + workspace (include/nd4hip.h). device=None -> current HIP device."""
+
+    def __init__(self, device=None):
+        self.lib = load()
+        self._h = ctypes.c_void_p()
+        check(self.lib.nd4hip_create(ctypes.byref(self._h), -1 if device is None else int(device)))
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.nd4hip_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        check(self.lib.nd4hip_synchronize(self._h))
+
+    def timer_start(self):
+        check(self.lib.nd4hip_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(self.lib.nd4hip_timer_stop(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self.lib.nd4hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def handle(device=None):
+    """Lazily created per-device default handle (the reference has no init step: SURVEY.md §3.5)."""
+    key = -1 if device is None else int(device)
+    with _lock:
+        h = _default.get(key)
+    if h is None:
+        h = Handle(device)
+        with _lock:
+            _default[key] = h
+    return h

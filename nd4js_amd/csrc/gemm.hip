@@ -1,0 +1,230 @@
+// fp64 GEMM for gfx950 (MI355X): C = alpha * op(A) * op(B) + beta * C, row-major, batched.
+//
+// Replaces the reference's scalar i-k-j triple loop (src/la/matmul.js:49-53) and is the
+// trailing-update engine of the blocked LU / QR / block-Jacobi kernels.
+//
+// Design:
+//  * 256-thread workgroup = 4 wave64 in a 2x2 grid; macro tile 128x128, K-step 16;
+//    each wave owns a 64x64 sub-tile = 4x4 accumulators of v_mfma_f64_16x16x4_f64
+//    (16 independent 64-cycle MFMA chains per wave -> the matrix pipe never waits on a dependency).
+//  * operand tiles are staged global -> registers -> LDS, double-buffered, ONE barrier per K-step:
+//    the global loads of step t+1 are issued before the 64 MFMAs of step t and written to the other
+//    LDS buffer after them. Two workgroups per CU (<= 256 VGPR, 72 KiB LDS each) cover each other's
+//    barrier / write phases.
+//  * LDS images are chosen so that every ds_read_b64 fragment read is bank-conflict free:
+//      "row" image  [128][17]  (operand stored x-major, k contiguous): lane (x=l&15,k=l>>4) ->
+//                   dword bank (34*x + 2*k) mod 64: 32 lanes x 2 dwords cover all 64 banks once;
+//      "kmaj" image [16][144]  (operand stored k-major, x contiguous): row stride 288 dwords
+//                   = 32 mod 64, so lanes 16-31 (next k) take the other half of the banks.
+//  * workgroup -> tile map is XCD-aware (blocks b, b+8, ... share an XCD's L2): each XCD gets a
+//    contiguous chunk of tiles, rasterised in groups of 8 tile-rows so the A/B panels it streams
+//    stay in its 4 MiB L2.
+//  * edges: rows/cols/k beyond the matrix are loaded as zeros (predicated loads) and never stored;
+//    the 16-byte vector path needs even leading dimensions / extents / offsets, otherwise the
+//    scalar path (8-byte loads) runs.
+#include "nd4hip_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDR = BK + 1;       // row image leading dim (doubles)
+constexpr int LDK = BN + 16;      // kmaj image leading dim (doubles)
+constexpr int TILE = BK * LDK;    // 2304 doubles >= BM*LDR = 2176: one operand buffer
+constexpr int NXCD = 8, GROUP_M = 8;
+
+struct GemmArgs {
+  const double* A; const double* B; double* C;
+  int M, N, K;
+  long lda, ldb, ldc, sA, sB, sC;
+  double alpha, beta;
+  int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging -------------------------------------------------------------
+// ROW operand: stored [x][k] (k contiguous). thread t covers x = q*32 + t/8, k = 2*(t%8)+{0,1}
+template <bool VEC>
+__device__ __forceinline__ void load_row(d2 (&r)[4], const double* __restrict__ P, long ld,
+                                         int x0, int X, int k0, int K, int t) {
+  const int kc = k0 + ((t & 7) << 1);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int x = x0 + q * 32 + (t >> 3);
+    const double* p = P + (long)x * ld + kc;
+    if (VEC) {
+      d2 v = {0.0, 0.0};
+      if (x < X && kc < K) v = *reinterpret_cast<const d2*>(p);
+      r[q] = v;
+    } else {
+      double a = 0.0, b = 0.0;
+      if (x < X && kc < K) a = p[0];
+      if (x < X && kc + 1 < K) b = p[1];
+      r[q].x = a; r[q].y = b;
+    }
+  }
+}
+__device__ __forceinline__ void store_row(double* S, const d2 (&r)[4], int t) {
+  const int kc = (t & 7) << 1;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double* s = S + (q * 32 + (t >> 3)) * LDR + kc;
+    s[0] = r[q].x; s[1] = r[q].y;
+  }
+}
+// KMAJ operand: stored [k][x] (x contiguous). thread t covers k = t/16, x = q*32 + 2*(t%16)+{0,1}
+template <bool VEC>
+__device__ __forceinline__ void load_kmaj(d2 (&r)[4], const double* __restrict__ P, long ld,
+                                          int x0, int X, int k0, int K, int t) {
+  const int k = k0 + (t >> 4);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int x = x0 + q * 32 + ((t & 15) << 1);
+    const double* p = P + (long)k * ld + x;
+    if (VEC) {
+      d2 v = {0.0, 0.0};
+      if (k < K && x < X) v = *reinterpret_cast<const d2*>(p);
+      r[q] = v;
+    } else {
+      double a = 0.0, b = 0.0;
+      if (k < K && x < X) a = p[0];
+      if (k < K && x + 1 < X) b = p[1];
+      r[q].x = a; r[q].y = b;
+    }
+  }
+}
+__device__ __forceinline__ void store_kmaj(double* S, const d2 (&r)[4], int t) {
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    *reinterpret_cast<d2*>(S + (t >> 4) * LDK + q * 32 + ((t & 15) << 1)) = r[q];
+}
+
+// TA: A is stored K x M (operand = transpose of the stored matrix); TB: B is stored N x K.
+template <bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * TILE];   // [buf][A|B][TILE]
+
+  // ---- XCD-aware tile assignment (bijective for any tile count) ----
+  const int nwg = g.tiles_m * g.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x, xcd = bid % NXCD, within = bid / NXCD;
+    const int q = nwg / NXCD, r = nwg % NXCD;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int per_group = GROUP_M * g.tiles_n;
+  const int first_m = (wg / per_group) * GROUP_M;
+  const int gsz = min(g.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (wg % per_group) % gsz;
+  const int tn = (wg % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const long bz = blockIdx.y;
+  const double* __restrict__ A = g.A + bz * g.sA;
+  const double* __restrict__ B = g.B + bz * g.sB;
+  double* __restrict__ C = g.C + bz * g.sC;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int fx = lane & 15, fk = lane >> 4;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[4], rb[4];
+  auto gload = [&](int k0) {
+    if (TA) load_kmaj<VEC>(ra, A, g.lda, m0, g.M, k0, g.K, t); else load_row<VEC>(ra, A, g.lda, m0, g.M, k0, g.K, t);
+    if (TB) load_row<VEC>(rb, B, g.ldb, n0, g.N, k0, g.K, t);  else load_kmaj<VEC>(rb, B, g.ldb, n0, g.N, k0, g.K, t);
+  };
+  auto sstore = [&](int buf) {
+    double* sa = lds + buf * 2 * TILE; double* sb = sa + TILE;
+    if (TA) store_kmaj(sa, ra, t); else store_row(sa, ra, t);
+    if (TB) store_row(sb, rb, t);  else store_kmaj(sb, rb, t);
+  };
+
+  const int nk = (g.K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);          // in flight during the MFMAs below
+    const double* sa = lds + cur * 2 * TILE;
+    const double* sb = sa + TILE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        a[i] = TA ? sa[(kk * 4 + fk) * LDK + wm + i * 16 + fx] : sa[(wm + i * 16 + fx) * LDR + kk * 4 + fk];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        b[j] = TB ? sb[(wn + j * 16 + fx) * LDR + kk * 4 + fk] : sb[(kk * 4 + fk) * LDK + wn + j * 16 + fx];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[row = (lane>>4) + 4r][col = lane&15] of each 16x16 tile ----
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = n0 + wn + j * 16 + fx;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm + i * 16 + fk + 4 * r;
+        if (row < g.M && col < g.N) {
+          double* c = C + (long)row * g.ldc + col;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+template <bool TA, bool TB>
+int launch(nd4hip_handle* h, const GemmArgs& g, bool vec, int64_t batch) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1), block(256, 1, 1);
+  if (vec) hipLaunchKernelGGL((dgemm_kernel<TA, TB, true>), grid, block, 0, h->stream, g);
+  else     hipLaunchKernelGGL((dgemm_kernel<TA, TB, false>), grid, block, 0, h->stream, g);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, int64_t K,
+             double alpha, const double* A, int64_t lda, int64_t sA,
+             const double* B, int64_t ldb, int64_t sB,
+             double beta, double* C, int64_t ldc, int64_t sC, int64_t batch) {
+  if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  ND4_CHECK_ARG(K >= 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "nd4_gemm: extent out of range");
+  ND4_CHECK_ARG(batch <= 65535, "nd4_gemm: batch %lld exceeds 65535 per launch", (long long)batch);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+  g.alpha = alpha; g.beta = beta;
+  g.tiles_m = (int)((M + BM - 1) / BM); g.tiles_n = (int)((N + BN - 1) / BN);
+  ND4_CHECK_ARG((int64_t)g.tiles_m * g.tiles_n < (1ll << 31), "nd4_gemm: too many tiles");
+  auto even = [](int64_t v) { return (v & 1) == 0; };
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // 16-byte loads need: aligned bases, even row strides / batch strides, and an even extent along
+  // the contiguous axis of each operand (so a 2-element chunk is never half out of range).
+  const bool vec = al16(A) && al16(B) && even(lda) && even(ldb) && even(sA) && even(sB) &&
+                   even(transA ? M : K) && even(transB ? K : N);
+  if (transA) return transB ? launch<true, true>(h, g, vec, batch) : launch<true, false>(h, g, vec, batch);
+  return transB ? launch<false, true>(h, g, vec, batch) : launch<false, false>(h, g, vec, batch);
+}

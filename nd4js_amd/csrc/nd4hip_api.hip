@@ -1,0 +1,149 @@
+// extern "C" entry points of include/nd4hip.h: argument validation, the *_dev (device pointer) forms
+// and the host-pointer forms (H2D -> kernels -> D2H) that the N-API shim binds.
+#include "nd4hip_internal.h"
+
+namespace {
+
+// Device staging for the host-pointer entry points: one hipMalloc'd arena per call site, freed on
+// return (these calls are PCIe-bound; allocation cost is noise next to the copies).
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    ND4_HIP(hipMalloc(&p, bytes ? bytes : 8));
+    return 0;
+  }
+};
+
+int h2d(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+int d2h(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+constexpr size_t D = sizeof(double);
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ matmul
+extern "C" int nd4hip_dgemm_batched_dev(nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
+                                        const double* A, int64_t strideA, const double* B, int64_t strideB, double* C) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && I >= 0 && K >= 0 && J >= 0, "nd4hip_dgemm_batched: negative extent");
+  ND4_CHECK_ARG(strideA == 0 || strideA >= I * K, "nd4hip_dgemm_batched: strideA must be 0 or >= I*K");
+  ND4_CHECK_ARG(strideB == 0 || strideB >= K * J, "nd4hip_dgemm_batched: strideB must be 0 or >= K*J");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(A && B && C, "nd4hip_dgemm_batched: NULL matrix pointer");
+  for (int64_t b0 = 0; b0 < batch; b0 += 32768) {             // gridDim.y limit
+    const int64_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
+    ND4_TRY(nd4_gemm(h, false, false, I, J, K, 1.0, A + b0 * strideA, K, strideA, B + b0 * strideB, J, strideB,
+                     0.0, C + b0 * I * J, J, I * J, nb));
+  }
+  return 0;
+}
+
+extern "C" int nd4hip_dgemm_batched(nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
+                                    const double* A, int64_t strideA, const double* B, int64_t strideB, double* C) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && I >= 0 && K >= 0 && J >= 0, "nd4hip_dgemm_batched: negative extent");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nA = (size_t)(strideA ? (batch - 1) * strideA + I * K : I * K);
+  const size_t nB = (size_t)(strideB ? (batch - 1) * strideB + K * J : K * J);
+  const size_t nC = (size_t)(batch * I * J);
+  DevBuf dA, dB, dC;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dB.alloc(nB * D)); ND4_TRY(dC.alloc(nC * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D)); ND4_TRY(h2d(h, dB.p, B, nB * D));
+  ND4_TRY(nd4hip_dgemm_batched_dev(h, batch, I, K, J, (const double*)dA.p, strideA, (const double*)dB.p, strideB, (double*)dC.p));
+  ND4_TRY(d2h(h, C, dC.p, nC * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                   double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                                   double beta, double* C, int64_t ldc) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_ex: NULL handle");
+  ND4_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "nd4hip_dgemm_ex: negative extent");
+  ND4_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "nd4hip_dgemm_ex: leading dimension too small");
+  if (M == 0 || N == 0) return 0;
+  return nd4_gemm(h, transA != 0, transB != 0, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
+}
+
+// ------------------------------------------------------------------------------------ LU
+extern "C" int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && LU && P, "nd4hip_dgetrf_batched: NULL pointer");
+  return nd4_getrf(h, batch, N, A, LU, P);
+}
+extern "C" int nd4hip_dgetrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)(batch * N * N);
+  DevBuf dA, dLU, dP;
+  ND4_TRY(dA.alloc(n * D)); ND4_TRY(dLU.alloc(n * D)); ND4_TRY(dP.alloc((size_t)(batch * N) * 4));
+  ND4_TRY(h2d(h, dA.p, A, n * D));
+  ND4_TRY(nd4hip_dgetrf_batched_dev(h, batch, N, (const double*)dA.p, (double*)dLU.p, (int32_t*)dP.p));
+  ND4_TRY(d2h(h, LU, dLU.p, n * D)); ND4_TRY(d2h(h, P, dP.p, (size_t)(batch * N) * 4));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ QR
+extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_q_batched: NULL pointer");
+  return nd4_geqrf_q(h, batch, M, N, A, Q, R);
+}
+extern "C" int nd4hip_dgeqrf_q_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const int64_t L = M < N ? M : N;
+  const size_t nA = (size_t)(batch * M * N), nQ = (size_t)(batch * M * L), nR = (size_t)(batch * L * N);
+  DevBuf dA, dQ, dR;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dQ.alloc(nQ * D)); ND4_TRY(dR.alloc(nR * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D));
+  ND4_TRY(nd4hip_dgeqrf_q_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dQ.p, (double*)dR.p));
+  ND4_TRY(d2h(h, Q, dQ.p, nQ * D)); ND4_TRY(d2h(h, R, dR.p, nR * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ SVD
+extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
+                                          double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgesvdj_batched: negative extent");
+  if (sweeps_out) *sweeps_out = 0;
+  if (offnorm_out) *offnorm_out = 0.0;
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && U && sv && V, "nd4hip_dgesvdj_batched: NULL pointer");
+  return nd4_gesvdj(h, batch, M, N, A, U, sv, V, sweeps_out, offnorm_out);
+}
+extern "C" int nd4hip_dgesvdj_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
+                                      double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgesvdj_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) { if (sweeps_out) *sweeps_out = 0; if (offnorm_out) *offnorm_out = 0; return 0; }
+  ND4_HIP(hipSetDevice(h->device));
+  const int64_t L = M < N ? M : N;
+  const size_t nA = (size_t)(batch * M * N), nU = (size_t)(batch * M * L), nS = (size_t)(batch * L), nV = (size_t)(batch * L * N);
+  DevBuf dA, dU, dS, dV;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dU.alloc(nU * D)); ND4_TRY(dS.alloc(nS * D)); ND4_TRY(dV.alloc(nV * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D));
+  ND4_TRY(nd4hip_dgesvdj_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dU.p, (double*)dS.p, (double*)dV.p,
+                                     sweeps_out, offnorm_out));
+  ND4_TRY(d2h(h, U, dU.p, nU * D)); ND4_TRY(d2h(h, sv, dS.p, nS * D)); ND4_TRY(d2h(h, V, dV.p, nV * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}

@@ -1,0 +1,205 @@
+// libnd4hip.so core: handle lifecycle, error reporting, memory, timing, synthetic-input fill and the
+// small copy / transpose / identity kernels shared by the decompositions.
+#include "nd4hip_internal.h"
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void nd4_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int nd4_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  nd4_set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return ND4HIP_ERR_HIP;
+}
+
+extern "C" const char* nd4hip_last_error(void) { return g_err; }
+extern "C" const char* nd4hip_version(void) { return "nd4hip 0.1.0 (gfx950)"; }
+
+extern "C" int nd4hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
+  ND4_CHECK_ARG(out != nullptr, "nd4hip_create: out is NULL");
+  *out = nullptr;
+  int n = nd4hip_device_count();
+  if (n <= 0) { nd4_set_error("nd4hip_create: no HIP device available"); return ND4HIP_ERR_NODEV; }
+  if (device < 0) ND4_HIP(hipGetDevice(&device));
+  ND4_CHECK_ARG(device < n, "nd4hip_create: device %d out of range (%d devices)", device, n);
+  ND4_HIP(hipSetDevice(device));
+  nd4hip_handle* h = new (std::nothrow) nd4hip_handle();
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_create: out of host memory");
+  h->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e != hipSuccess) { nd4hip_destroy(h); return nd4_hip_fail(e, "stream/event create", __FILE__, __LINE__); }
+  h->stream = h->own_stream;
+  *out = h;
+  return 0;
+}
+
+extern "C" void nd4hip_destroy(nd4hip_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" int nd4hip_set_stream(nd4hip_handle* h, void* s) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_set_stream: NULL handle");
+  h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own_stream;
+  return 0;
+}
+extern "C" int nd4hip_synchronize(nd4hip_handle* h) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_synchronize: NULL handle");
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int nd4_workspace(nd4hip_handle* h, size_t bytes, void** out) {
+  if (bytes > h->ws_bytes) {
+    ND4_HIP(hipStreamSynchronize(h->stream));          // nothing may still use the old block
+    if (h->ws) { ND4_HIP(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    ND4_HIP(hipMalloc(&h->ws, want));
+    h->ws_bytes = want;
+  }
+  *out = h->ws;
+  return 0;
+}
+int nd4_pinned(nd4hip_handle* h, size_t bytes, void** out) {
+  if (bytes > h->pinned_bytes) {
+    if (h->pinned) { ND4_HIP(hipHostFree(h->pinned)); h->pinned = nullptr; h->pinned_bytes = 0; }
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    ND4_HIP(hipHostMalloc(&h->pinned, want, hipHostMallocDefault));
+    h->pinned_bytes = want;
+  }
+  *out = h->pinned;
+  return 0;
+}
+
+extern "C" int nd4hip_malloc(nd4hip_handle* h, size_t bytes, void** p) {
+  ND4_CHECK_ARG(h && p, "nd4hip_malloc: NULL argument");
+  ND4_HIP(hipSetDevice(h->device));
+  ND4_HIP(hipMalloc(p, bytes ? bytes : 8));
+  return 0;
+}
+extern "C" int nd4hip_free(nd4hip_handle* h, void* p) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_free: NULL handle");
+  if (p) { ND4_HIP(hipStreamSynchronize(h->stream)); ND4_HIP(hipFree(p)); }
+  return 0;
+}
+extern "C" int nd4hip_memcpy_h2d(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_memcpy_h2d: NULL handle");
+  if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int nd4hip_memcpy_d2h(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_memcpy_d2h: NULL handle");
+  if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nd4hip_timer_start(nd4hip_handle* h) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_timer_start: NULL handle");
+  ND4_HIP(hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+extern "C" int nd4hip_timer_stop(nd4hip_handle* h, float* ms) {
+  ND4_CHECK_ARG(h && ms, "nd4hip_timer_stop: NULL argument");
+  ND4_HIP(hipEventRecord(h->ev1, h->stream));
+  ND4_HIP(hipEventSynchronize(h->ev1));
+  ND4_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+// ---------------------------------------------------------------- synthetic inputs
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; return x;
+}
+__global__ void fill_uniform_kernel(uint32_t seed, uint32_t offset, int64_t n, double* __restrict__ out) {
+  const uint32_t s = fmix32(seed);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t idx = offset + (uint32_t)i;
+    const uint32_t hi = fmix32(idx ^ s);
+    const uint32_t lo = fmix32(hi + 0x9E3779B9u + idx);
+    const double m = (double)(hi >> 5) * 67108864.0 + (double)(lo >> 6);
+    out[i] = m * 0x1p-52 - 1.0;
+  }
+}
+extern "C" int nd4hip_fill_uniform_dev(nd4hip_handle* h, uint32_t seed, uint32_t offset, int64_t n, double* out) {
+  ND4_CHECK_ARG(h && (out || n == 0) && n >= 0, "nd4hip_fill_uniform_dev: bad argument");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, seed, offset, n, out);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- small matrix utilities
+__global__ void copy_matrix_kernel(int64_t rows, int64_t cols, const double* __restrict__ src, int64_t lds,
+                                   double* __restrict__ dst, int64_t ldd, int64_t ssrc, int64_t sdst) {
+  src += blockIdx.z * ssrc; dst += blockIdx.z * sdst;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) dst[r * ldd + c] = src[r * lds + c];
+}
+int nd4_copy_matrix(nd4hip_handle* h, int64_t rows, int64_t cols, const double* src, int64_t lds,
+                    double* dst, int64_t ldd, int64_t batch, int64_t ssrc, int64_t sdst) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 1024 ? rows : 1024), (unsigned)batch);
+  hipLaunchKernelGGL(copy_matrix_kernel, grid, dim3(256), 0, h->stream, rows, cols, src, lds, dst, ldd, ssrc, sdst);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+// dst[c][r] = src[r][c], 32x32 tiles through LDS (padded: conflict-free both ways)
+__global__ void transpose_kernel(int64_t rows, int64_t cols, const double* __restrict__ src, int64_t lds,
+                                 double* __restrict__ dst, int64_t ldd, int64_t ssrc, int64_t sdst) {
+  __shared__ double tile[32][33];
+  src += blockIdx.z * ssrc; dst += blockIdx.z * sdst;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 32 x 8
+  const int64_t c0 = blockIdx.x * 32ll, r0 = blockIdx.y * 32ll;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(r0 + i) * lds + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) dst[(c0 + i) * ldd + r0 + tx] = tile[tx][i];
+}
+int nd4_transpose(nd4hip_handle* h, int64_t rows, int64_t cols, const double* src, int64_t lds,
+                  double* dst, int64_t ldd, int64_t batch, int64_t ssrc, int64_t sdst) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, rows, cols, src, lds, dst, ldd, ssrc, sdst);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void identity_kernel(int64_t rows, int64_t cols, double* __restrict__ dst, int64_t ldd, int64_t sdst) {
+  dst += blockIdx.z * sdst;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) dst[r * ldd + c] = (r == c) ? 1.0 : 0.0;
+}
+int nd4_set_identity(nd4hip_handle* h, int64_t rows, int64_t cols, double* dst, int64_t ldd,
+                     int64_t batch, int64_t sdst) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 1024 ? rows : 1024), (unsigned)batch);
+  hipLaunchKernelGGL(identity_kernel, grid, dim3(256), 0, h->stream, rows, cols, dst, ldd, sdst);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}

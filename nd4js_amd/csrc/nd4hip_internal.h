@@ -1,0 +1,53 @@
+// Internal declarations shared by the libnd4hip.so translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include "../../include/nd4hip.h"
+
+struct nd4hip_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;   // created by nd4hip_create
+  hipStream_t stream = nullptr;       // the stream work is enqueued on (own or caller's)
+  void* ws = nullptr;                 // growable device workspace
+  size_t ws_bytes = 0;
+  void* pinned = nullptr;             // small pinned host buffer for scalar read-backs
+  size_t pinned_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+};
+
+void nd4_set_error(const char* fmt, ...);
+int  nd4_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define ND4_HIP(expr)                                                           \
+  do { hipError_t _e = (expr);                                                  \
+       if (_e != hipSuccess) return nd4_hip_fail(_e, #expr, __FILE__, __LINE__); } while (0)
+#define ND4_CHECK_ARG(cond, ...)                                                \
+  do { if (!(cond)) { nd4_set_error(__VA_ARGS__); return ND4HIP_ERR_ARG; } } while (0)
+#define ND4_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
+
+// workspace: returns a device pointer valid until the next nd4_workspace call with a larger size
+int nd4_workspace(nd4hip_handle* h, size_t bytes, void** out);
+int nd4_pinned(nd4hip_handle* h, size_t bytes, void** out);
+
+// ---- internal launchers (device pointers, enqueue on h->stream) --------------------------------
+// C = alpha*op(A)*op(B) + beta*C, batched over gridDim.y with element strides sA/sB/sC
+int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, int64_t K,
+             double alpha, const double* A, int64_t lda, int64_t sA,
+             const double* B, int64_t ldb, int64_t sB,
+             double beta, double* C, int64_t ldc, int64_t sC, int64_t batch);
+
+int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
+               double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
+
+// small utility kernels (nd4hip_core.hip)
+int nd4_copy_matrix(nd4hip_handle* h, int64_t rows, int64_t cols, const double* src, int64_t lds,
+                    double* dst, int64_t ldd, int64_t batch, int64_t ssrc, int64_t sdst);
+int nd4_transpose(nd4hip_handle* h, int64_t rows, int64_t cols, const double* src, int64_t lds,
+                  double* dst, int64_t ldd, int64_t batch, int64_t ssrc, int64_t sdst);
+int nd4_set_identity(nd4hip_handle* h, int64_t rows, int64_t cols, double* dst, int64_t ldd,
+                     int64_t batch, int64_t sdst);

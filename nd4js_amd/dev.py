@@ -1,0 +1,116 @@
+"""Device-resident form of the hot path: the same C ABI (`*_dev` entry points) on torch CUDA tensors.
+
+PyTorch is plumbing only (device memory + the current HIP stream + torch.distributed); every
+kernel that runs is from libnd4hip.so. Tensors must be float64, contiguous, on a HIP device.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _h(t):
+    h = _lib.handle(t.device.index)
+    h.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+    return h
+
+
+def _chk(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous float64 CUDA tensor" % name)
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _batch(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+def fill_uniform(seed, shape, device="cuda", offset=0):
+    out = torch.empty(shape, dtype=torch.float64, device=device)
+    h = _h(out)
+    _lib.check(h.lib.nd4hip_fill_uniform_dev(h.ptr, seed, offset, out.numel(), _p(out)))
+    return out
+
+
+def matmul2(a, b, out=None):
+    """[..., I, K] x [..., K, J]; leading dims must be equal or one operand plain 2-D (broadcast)."""
+    _chk(a, "a"), _chk(b, "b")
+    I, K = a.shape[-2:]
+    J = b.shape[-1]
+    if b.shape[-2] != K:
+        raise ValueError("The last dimension of A and the 2nd to last dimension of B do not match.")
+    la, lb = tuple(a.shape[:-2]), tuple(b.shape[:-2])
+    if la == lb:
+        lead, sA, sB = la, I * K, K * J
+    elif _batch(lb) == 1:
+        lead, sA, sB = la, I * K, 0
+    elif _batch(la) == 1:
+        lead, sA, sB = lb, 0, K * J
+    else:
+        raise ValueError("Shapes are not broadcast-compatible.")   # general broadcasting: host wrapper (la.py)
+    batch = _batch(lead)
+    if out is None:
+        out = torch.empty(lead + (I, J), dtype=torch.float64, device=a.device)
+    h = _h(a)
+    _lib.check(h.lib.nd4hip_dgemm_batched_dev(h.ptr, batch, I, K, J, _p(a), sA if batch > 1 else 0,
+                                              _p(b), sB if batch > 1 else 0, _p(_chk(out, "out"))))
+    return out
+
+
+def gemm_ex(transA, transB, alpha, A, B, beta, C, M, N, K, lda, ldb, ldc):
+    h = _h(C)
+    _lib.check(h.lib.nd4hip_dgemm_ex_dev(h.ptr, int(transA), int(transB), M, N, K, alpha, _p(A), lda, _p(B), ldb,
+                                         beta, _p(C), ldc))
+    return C
+
+
+def lu_decomp(A):
+    _chk(A, "A")
+    N = A.shape[-1]
+    if A.dim() < 2 or A.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    LU = torch.empty_like(A)
+    P = torch.empty(A.shape[:-1], dtype=torch.int32, device=A.device)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgetrf_batched_dev(h.ptr, _batch(A.shape[:-2]), N, _p(A), _p(LU), ctypes.c_void_p(P.data_ptr())))
+    return LU, P
+
+
+def qr_decomp(A):
+    _chk(A, "A")
+    if A.dim() < 2:
+        raise ValueError("qr_decomp(A): A.ndim must be at least 2.")
+    M, N = A.shape[-2:]
+    L = min(M, N)
+    Q = torch.empty(tuple(A.shape[:-2]) + (M, L), dtype=torch.float64, device=A.device)
+    R = torch.empty(tuple(A.shape[:-2]) + (L, N), dtype=torch.float64, device=A.device)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgeqrf_q_batched_dev(h.ptr, _batch(A.shape[:-2]), M, N, _p(A), _p(Q), _p(R)))
+    return Q, R
+
+
+def svd_decomp(A, info=None):
+    _chk(A, "A")
+    if A.dim() < 2:
+        raise ValueError("svd_decomp(A): A.ndim must be at least 2.")
+    M, N = A.shape[-2:]
+    L = min(M, N)
+    lead = tuple(A.shape[:-2])
+    U = torch.empty(lead + (M, L), dtype=torch.float64, device=A.device)
+    sv = torch.empty(lead + (L,), dtype=torch.float64, device=A.device)
+    V = torch.empty(lead + (L, N), dtype=torch.float64, device=A.device)
+    sweeps, off = ctypes.c_int(0), ctypes.c_double(0.0)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgesvdj_batched_dev(h.ptr, _batch(lead), M, N, _p(A), _p(U), _p(sv), _p(V),
+                                                ctypes.byref(sweeps), ctypes.byref(off)))
+    if info is not None:
+        info["sweeps"], info["offnorm"] = sweeps.value, off.value
+    return U, sv, V

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: libnd4hip.so loads, exports every symbol that
+include/nd4hip.h declares, and the product path fails LOUDLY (no CPU fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from nd4js_amd import _lib, la
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "nd4hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nd4hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libnd4hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.nd4hip_version()
+
+
+def test_napi_shim_binds_the_same_abi():
+    shim = os.path.join(ROOT, "nd4js_amd", "csrc", "napi_shim.c")
+    if not os.path.exists(shim):
+        pytest.skip("shim not written yet")
+    src = open(shim).read()
+    for n in ("nd4hip_create", "nd4hip_dgemm_batched", "nd4hip_dgetrf_batched", "nd4hip_dgeqrf_q_batched",
+              "nd4hip_dgesvdj_batched", "nd4hip_last_error"):
+        assert n in src
+
+
+@pytest.mark.skipif(_lib.load().nd4hip_device_count() > 0, reason="GPU present")
+def test_no_cpu_fallback_without_gpu():
+    with pytest.raises(_lib.Nd4HipError) as e:
+        la.matmul2(np.eye(4), np.eye(4))
+    assert e.value.code == -4 and "no HIP device" in str(e.value)
+    for fn in (la.qr_decomp, la.lu_decomp, la.svd_decomp):
+        with pytest.raises(_lib.Nd4HipError):
+            fn(np.eye(4))
+
+
+def test_host_wrapper_errors_match_reference_text():
+    # argument validation happens before any device work (matmul.js:95-116, qr.js:83, lu.js:32)
+    with pytest.raises(ValueError, match="A must be at least 2D."):
+        la.matmul2(np.ones(3), np.ones((3, 3)))
+    with pytest.raises(ValueError, match="B must be at least 2D."):
+        la.matmul2(np.ones((3, 3)), np.ones(3))
+    with pytest.raises(ValueError, match="do not match"):
+        la.matmul2(np.ones((2, 3)), np.ones((4, 2)))
+    with pytest.raises(ValueError, match="broadcast-compatible"):
+        la.matmul2(np.ones((2, 2, 3)), np.ones((3, 3, 2)))
+    with pytest.raises(ValueError, match="at least 2"):
+        la.qr_decomp(np.ones(3))
+    with pytest.raises(ValueError, match="quadratic"):
+        la.lu_decomp(np.ones((2, 3)))
+    with pytest.raises(TypeError, match="must be float"):
+        la.svd_decomp(np.ones((2, 2), dtype=np.complex128))
+    with pytest.raises(TypeError):
+        la.matmul2(np.ones((2, 2), dtype=np.float32), np.ones((2, 2)))
+
+
+def test_broadcast_grouping_covers_every_batch_member():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        nb = rng.integers(0, 4)
+        lead = tuple(int(x) for x in rng.integers(1, 4, nb))
+        la_ = tuple(s if rng.random() < 0.6 else 1 for s in lead)[rng.integers(0, nb + 1):]
+        lb_ = tuple(s if rng.random() < 0.6 else 1 for s in lead)[rng.integers(0, nb + 1):]
+        lead = np.broadcast_shapes(la_, lb_)
+        IK, KJ = 6, 10
+        a_idx = np.broadcast_to((np.arange(int(np.prod(la_))) * IK).reshape(la_), lead).reshape(-1)
+        b_idx = np.broadcast_to((np.arange(int(np.prod(lb_))) * KJ).reshape(lb_), lead).reshape(-1)
+        seen = 0
+        for cnt, offA, sA, offB, sB, offC in la._bcast_groups(tuple(lead), la_, lb_, IK, KJ):
+            assert offC == seen and sA in (0, IK) and sB in (0, KJ)
+            for k in range(cnt):
+                assert a_idx[offC + k] == offA + k * sA and b_idx[offC + k] == offB + k * sB
+            seen += cnt
+        assert seen == a_idx.size
