@@ -37,9 +37,10 @@ int  nd4hip_device_count(void);
 /* device < 0: use the current HIP device. Creates a private non-blocking stream. */
 int  nd4hip_create(nd4hip_handle** out, int device);
 void nd4hip_destroy(nd4hip_handle* h);
-/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
- * the private stream. */
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). NULL is a
+ * valid value: HIP's default (null) stream. nd4hip_reset_stream goes back to the private stream. */
 int  nd4hip_set_stream(nd4hip_handle* h, void* hip_stream);
+int  nd4hip_reset_stream(nd4hip_handle* h);
 int  nd4hip_synchronize(nd4hip_handle* h);
 const char* nd4hip_last_error(void);
 const char* nd4hip_version(void);

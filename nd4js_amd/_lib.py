@@ -21,6 +21,7 @@ SIGNATURES = {
     "nd4hip_create": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int]),
     "nd4hip_destroy": (None, [ctypes.c_void_p]),
     "nd4hip_set_stream": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nd4hip_reset_stream": (c_int, [ctypes.c_void_p]),
     "nd4hip_synchronize": (c_int, [ctypes.c_void_p]),
     "nd4hip_last_error": (ctypes.c_char_p, []),
     "nd4hip_version": (ctypes.c_char_p, []),
@@ -91,6 +92,9 @@ class Handle:
 
     def set_stream(self, stream_ptr):
         check(self.lib.nd4hip_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        check(self.lib.nd4hip_reset_stream(self._h))
 
     def synchronize(self):
         check(self.lib.nd4hip_synchronize(self._h))

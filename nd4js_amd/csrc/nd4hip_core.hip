@@ -59,7 +59,12 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
 
 extern "C" int nd4hip_set_stream(nd4hip_handle* h, void* s) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_set_stream: NULL handle");
-  h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own_stream;
+  h->stream = reinterpret_cast<hipStream_t>(s);     // NULL = HIP's default stream
+  return 0;
+}
+extern "C" int nd4hip_reset_stream(nd4hip_handle* h) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_reset_stream: NULL handle");
+  h->stream = h->own_stream;
   return 0;
 }
 extern "C" int nd4hip_synchronize(nd4hip_handle* h) {
