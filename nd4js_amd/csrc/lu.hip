@@ -1,4 +1,275 @@
+// Blocked right-looking LU with partial (row) pivoting on row-major fp64 matrices, batched.
+//
+// Replaces src/la/lu.js:24-81 (unblocked Doolittle, first-maximum row pivoting, full-row swaps,
+// permutation VECTOR output). Per block column of width NB = 16:
+//   lu_panel   one workgroup per matrix factors rows [j0,N) x cols [j0,j0+nb): per column a
+//              wave-shuffle + LDS arg-max (ties -> lowest row, exactly the reference's strict '>' scan,
+//              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. 16 lanes own one row
+//              (one lane per panel column) so every row access is one coalesced 128-byte line.
+//              The fast variant keeps the whole panel in registers (<= 48 rows x 1 column per lane).
+//   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61
+//              swaps full rows), one thread per column -> coalesced.
+//   lu_trsm    U12 = L11^-1 * A12 (unit lower 16x16 in LDS, one thread per column).
+//   nd4_gemm   A22 -= L21 * U12 on the fp64 MFMA GEMM (gemm.hip).
 #include "nd4hip_internal.h"
-int nd4_getrf(nd4hip_handle*, int64_t, int64_t, const double*, double*, int32_t*) {
-  nd4_set_error("nd4_getrf: not implemented yet"); return ND4HIP_ERR_ARG;
+#include <cfloat>
+
+namespace {
+
+constexpr int NB = 16;          // panel width == lanes per row
+constexpr int RMAX = 48;        // register-resident rows per lane group (m <= 64 groups * 48 = 3072)
+
+struct PivCand { double mag; int idx; };
+
+__device__ __forceinline__ PivCand better(PivCand a, PivCand b) {
+  // larger magnitude wins; equal magnitude -> lower row index (first maximum, lu.js:50-52)
+  return (b.mag > a.mag || (b.mag == a.mag && b.idx < a.idx)) ? b : a;
+}
+__device__ __forceinline__ double pivot_mag(double x, int r, int jc) {
+  double m = fabs(x);
+  // NaN never wins the reference's `abs(x) > abs(cur)` scan, unless it is the start row itself
+  if (m != m) m = (r == jc) ? DBL_MAX * 2.0 /* +inf */ : -1.0;
+  return m;
+}
+
+// block-wide arg-max over candidates; result broadcast through *s_piv
+__device__ __forceinline__ int block_argmax(PivCand c, PivCand* s_red, int* s_piv, int t, int T) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    PivCand o;
+    o.mag = __shfl_xor(c.mag, off);
+    o.idx = __shfl_xor(c.idx, off);
+    c = better(c, o);
+  }
+  const int wave = t >> 6, nw = (T + 63) >> 6;
+  if ((t & 63) == 0) s_red[wave] = c;
+  __syncthreads();
+  if (t == 0) {
+    PivCand b = s_red[0];
+    for (int w = 1; w < nw; w++) b = better(b, s_red[w]);
+    *s_piv = b.idx;
+  }
+  __syncthreads();
+  return *s_piv;
+}
+
+// ---- general panel kernel: panel lives in global memory (any m) ------------------------------
+__global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+  __shared__ PivCand s_red[16];
+  __shared__ int s_piv;
+  __shared__ double s_u[NB];
+  double* A = LU + blockIdx.x * strideM;
+  int32_t* p = P + (long)blockIdx.x * N;
+  int32_t* ip = ipiv + (long)blockIdx.x * N;
+  const int t = threadIdx.x, T = blockDim.x;
+  const int c = t & (NB - 1), g = t >> 4, G = T >> 4;
+
+  for (int k = 0; k < nb; k++) {
+    const int jc = j0 + k;
+    PivCand cand{-2.0, 0x7fffffff};
+    for (int r = jc + t; r < N; r += T) {
+      PivCand o{pivot_mag(A[(long)r * N + jc], r, jc), r};
+      cand = better(cand, o);
+    }
+    const int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    if (t == 0) {
+      ip[jc] = piv;
+      if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
+    }
+    if (piv != jc && t < nb) {
+      double* a = A + (long)jc * N + j0 + t; double* b = A + (long)piv * N + j0 + t;
+      const double x = *a; *a = *b; *b = x;
+    }
+    __syncthreads();
+    if (t < nb) s_u[t] = A[(long)jc * N + j0 + t];
+    __syncthreads();
+    const double pv = s_u[k], uc = (c < nb) ? s_u[c] : 0.0;
+    for (int r = jc + 1 + g; r < N; r += G) {
+      double* row = A + (long)r * N + j0;
+      const double l = row[k] / pv;                  // lu.js:68
+      if (c == k) row[k] = l;
+      else if (c > k && c < nb) row[c] -= l * uc;    // lu.js:71-72
+    }
+    __syncthreads();
+  }
+}
+
+// ---- fast panel kernel: the panel (m <= 64*RMAX rows x 16 cols) lives in registers -------------
+// lane group g (16 lanes) owns rows j0 + g + 64*i; lane c of the group owns column j0 + c.
+template <int R>
+__global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+  __shared__ PivCand s_red[16];
+  __shared__ int s_piv;
+  __shared__ double s_u[NB], s_j[NB];
+  double* A = LU + blockIdx.x * strideM;
+  int32_t* p = P + (long)blockIdx.x * N;
+  int32_t* ip = ipiv + (long)blockIdx.x * N;
+  const int t = threadIdx.x, T = 1024;
+  const int c = t & (NB - 1), g = t >> 4;
+  const bool col_ok = c < nb;
+
+  double a[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + g + 64 * i;
+    a[i] = (r < N && col_ok) ? A[(long)r * N + j0 + c] : 0.0;
+  }
+
+  // Rows beyond N hold zeros: they can never win the arg-max against a valid row (lower index wins
+  // ties) and are never stored, so the inner loops carry no per-row bounds predicate. Only slot 0
+  // (rows j0 + g, g < 64) can contain already-factored rows (k < 16 <= 64).
+  for (int k = 0; k < nb; k++) {
+    const int jc = j0 + k;
+    // arg-max over column k: held by lanes c == k
+    PivCand cand{-2.0, 0x7fffffff};
+    if (c == k) {
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + g + 64 * i;
+        PivCand o{pivot_mag(a[i], r, jc), r};
+        if (i == 0 && g < k) o.mag = -2.0;
+        if (r >= N) o.mag = -2.0;
+        cand = better(cand, o);
+      }
+    }
+    const int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    if (t == 0) {
+      ip[jc] = piv;
+      if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
+    }
+    // publish the pivot row (its owner group) and, if it moves, the displaced row jc
+    const int pg = (piv - j0) & 63, pi = (piv - j0) >> 6;     // owner group / slot of row piv
+    double mine_piv = a[0];
+#pragma unroll
+    for (int i = 1; i < R; i++) mine_piv = (i == pi) ? a[i] : mine_piv;
+    if (g == pg && col_ok) s_u[c] = mine_piv;
+    if (g == k && col_ok) s_j[c] = a[0];                      // row jc = j0 + k lives in group k, slot 0
+    __syncthreads();
+    if (piv != jc) {                                          // swap rows jc <-> piv inside the panel
+      const double from_jc = s_j[c], from_piv = s_u[c];
+      if (g == pg) {
+#pragma unroll
+        for (int i = 0; i < R; i++) a[i] = (i == pi) ? from_jc : a[i];
+      }
+      if (g == k) a[0] = from_piv;
+    }
+    const double pv = s_u[k], uc = s_u[c];
+    {                                                         // slot 0: rows j0+g, only g > k are below the pivot
+      const double l = __shfl(a[0], (threadIdx.x & 48) | k, 64) / pv;
+      const double upd = (c == k) ? l : ((c > k) ? a[0] - l * uc : a[0]);
+      a[0] = (g > k) ? upd : a[0];
+    }
+#pragma unroll
+    for (int i = 1; i < R; i++) {
+      const double l = __shfl(a[i], (threadIdx.x & 48) | k, 64) / pv;
+      a[i] = (c == k) ? l : ((c > k) ? a[i] - l * uc : a[i]);
+    }
+    __syncthreads();       // s_u / s_j / s_red reused next column
+  }
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + g + 64 * i;
+    if (r < N && col_ok) A[(long)r * N + j0 + c] = a[i];
+  }
+}
+
+// ---- apply the panel's row swaps to the columns outside the panel ------------------------------
+__global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, long strideM, int j0, int nb, const int32_t* __restrict__ ipiv) {
+  double* A = LU + blockIdx.y * strideM;
+  const int32_t* ip = ipiv + (long)blockIdx.y * N;
+  int col = blockIdx.x * blockDim.x + threadIdx.x;       // index among the N - nb outside columns
+  if (col >= N - nb) return;
+  if (col >= j0) col += nb;
+  for (int k = 0; k < nb; k++) {
+    const int r = j0 + k, pv = ip[r];
+    if (pv != r) {
+      const double x = A[(long)r * N + col];
+      A[(long)r * N + col] = A[(long)pv * N + col];
+      A[(long)pv * N + col] = x;
+    }
+  }
+}
+
+// ---- U12 = L11^-1 * A12, L11 unit lower nb x nb at (j0,j0); A12 = rows j0.. , cols [c0, N) -------
+__global__ __launch_bounds__(256) void lu_trsm(double* __restrict__ LU, int N, long strideM, int j0, int nb) {
+  __shared__ double s_l[NB][NB + 1];
+  double* A = LU + blockIdx.y * strideM;
+  const int t = threadIdx.x;
+  if (t < NB * NB) {
+    const int i = t / NB, j = t % NB;
+    s_l[i][j] = (i < nb && j < i) ? A[(long)(j0 + i) * N + j0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int col = j0 + nb + blockIdx.x * blockDim.x + t;
+  if (col >= N) return;
+  double x[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) x[i] = (i < nb) ? A[(long)(j0 + i) * N + col] : 0.0;
+#pragma unroll
+  for (int i = 1; i < NB; i++) {
+    double s = x[i];
+#pragma unroll
+    for (int j = 0; j < i; j++) s -= s_l[i][j] * x[j];      // same order as lu.js:71-72 applied column-wise
+    x[i] = s;
+  }
+#pragma unroll
+  for (int i = 1; i < NB; i++)
+    if (i < nb) A[(long)(j0 + i) * N + col] = x[i];
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ P, int N, long total) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < total) P[i] = (int32_t)(i % N);
+}
+
+template <int R>
+void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch) {
+  hipLaunchKernelGGL((lu_panel_reg<R>), dim3(batch), dim3(1024), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+}
+
+}  // namespace
+
+int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, double* LU, int32_t* P) {
+  ND4_CHECK_ARG(N64 < (1ll << 30) && batch < 65536, "nd4_getrf: extent out of range");
+  const int N = (int)N64;
+  const long strideM = (long)N * N;
+  if (LU != A) ND4_HIP(hipMemcpyAsync(LU, A, sizeof(double) * batch * strideM, hipMemcpyDeviceToDevice, h->stream));
+  const long total = (long)batch * N;
+  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, N, total);
+  void* ws = nullptr;
+  ND4_TRY(nd4_workspace(h, sizeof(int32_t) * total, &ws));
+  int32_t* ipiv = static_cast<int32_t*>(ws);
+
+  for (int j0 = 0; j0 < N; j0 += NB) {
+    const int nb = N - j0 < NB ? N - j0 : NB;
+    const int m = N - j0;
+    if (m >= 256 && m <= 64 * RMAX) {
+      const int R = (m + 63) / 64;
+      if (R <= 8)       launch_panel_reg<8>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      else if (R <= 16) launch_panel_reg<16>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      else if (R <= 32) launch_panel_reg<32>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      else              launch_panel_reg<RMAX>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+    } else {
+      int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
+      hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+    }
+    if (N > nb)
+      hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                         LU, N, strideM, j0, nb, ipiv);
+    const int rest = N - j0 - nb;
+    if (rest > 0) {
+      hipLaunchKernelGGL(lu_trsm, dim3((unsigned)((rest + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                         LU, N, strideM, j0, nb);
+      ND4_HIP(hipGetLastError());
+      double* base = LU;
+      ND4_TRY(nd4_gemm(h, false, false, rest, rest, nb, -1.0,
+                       base + (long)(j0 + nb) * N + j0, N, strideM,
+                       base + (long)j0 * N + j0 + nb, N, strideM,
+                       1.0, base + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
+    }
+  }
+  ND4_HIP(hipGetLastError());
+  return 0;
 }

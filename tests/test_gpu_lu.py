@@ -1,0 +1,105 @@
+"""GPU parity of lu_decomp through the C ABI: identical permutation vector,
+LU within 1e-10 norm-wise (asserted tighter), reference test properties (lu_test.js:56-69)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_cases
+from families import make_input
+from nd4js_amd import rng
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-10
+
+
+def relerr(x, ref):
+    return np.linalg.norm((x - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def la():
+    from nd4js_amd import la as _la
+    return _la
+
+
+def check_properties(a, lu, p):
+    """L*U == A[P,:] and max|L| <= 1 (partial-pivot property, lu_test.js:56-69)."""
+    N = a.shape[-1]
+    L = np.tril(lu, -1) + np.eye(N)
+    U = np.triu(lu)
+    ap = np.take_along_axis(a, p[..., None].astype(np.int64), axis=-2)
+    assert relerr(L @ U, ap) <= 1e-13 * max(N, 8)
+    assert np.abs(np.tril(lu, -1)).max(initial=0.0) <= 1.0
+    assert np.array_equal(np.sort(p, axis=-1), np.broadcast_to(np.arange(N), p.shape))
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases(op="lu_decomp") if not c.startswith("c3_")])
+def test_golden(la, golden, name):
+    g = golden(name)
+    a = make_input(g.seed, g.shape, g.family)
+    lu, p = la.lu_decomp(a)
+    assert p.dtype == np.int32 and np.array_equal(p, g["P"])
+    ref = g["LU"]
+    if np.isfinite(ref).all():
+        assert relerr(lu, ref) <= 1e-13
+    else:
+        assert np.array_equal(np.isfinite(lu), np.isfinite(ref))
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 15, 16, 17, 31, 33, 100, 255, 256, 257, 300, 511, 777, 1024, 1100])
+def test_vs_oracle(la, N):
+    a = rng.matrix(700 + N, N, N)
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a)
+    assert np.array_equal(p, rp)
+    assert relerr(lu, rlu) <= 1e-12
+    check_properties(a, lu, p)
+
+
+def test_batched(la):
+    a = rng.matrix(801, 6, 3, 45, 45)
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a)
+    assert lu.shape == a.shape and p.shape == a.shape[:-1]
+    assert np.array_equal(p, rp) and relerr(lu, rlu) <= 1e-12
+    b = rng.matrix(802, 5, 300, 300)
+    lu, p = la.lu_decomp(b)
+    rlu, rp = oracle.lu_decomp(b)
+    assert np.array_equal(p, rp) and relerr(lu, rlu) <= 1e-12
+
+
+def test_ties_pick_first_maximum(la):
+    a = np.ones((40, 40))
+    a += np.triu(np.ones((40, 40)), 1) * 0.5
+    a[5:, 3] = -1.0              # equal magnitudes, mixed signs
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a)
+    assert np.array_equal(p, rp)
+    assert np.allclose(lu, rlu, rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_int32_input_is_promoted(la):
+    a = (rng.matrix(803, 20, 20) * 50).astype(np.int32)
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a.astype(np.float64))
+    assert lu.dtype == np.float64 and np.array_equal(p, rp) and relerr(lu, rlu) <= 1e-12
+
+
+def test_beyond_register_panel(la):
+    """N > 3072: the first panels run the global-memory panel kernel."""
+    N = 3200
+    a = rng.matrix(804, N, N)
+    lu, p = la.lu_decomp(a)
+    check_properties(a, lu, p)
+
+
+def test_c3_2048_against_reference(la, golden):
+    g = golden("c3_lu2048")
+    N = g.shape[-1]
+    a = rng.matrix(g.seed, N, N)
+    lu, p = la.lu_decomp(a)
+    assert np.array_equal(p, g["P"])
+    got, val = lu.reshape(-1)[g["LUidx"]], g["LUval"]
+    assert np.linalg.norm(got - val) / np.linalg.norm(val) <= 1e-11
+    assert abs(np.linalg.norm(lu) - g.froLU) <= 1e-11 * g.froLU
+    check_properties(a, lu, p)
