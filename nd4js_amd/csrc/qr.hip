@@ -1,4 +1,413 @@
+// Blocked Householder QR with explicit Q on row-major fp64 matrices, batched, with the reference's
+// Givens sign convention restored afterwards.
+//
+// Replaces src/la/qr.js:27-77 (qr_decomp_full, Givens, cache-blocked loop order) / :80-145
+// (qr_decomp). The GPU algorithm is different (compact-WY Householder); the contract that is kept
+// is the OUTPUT: for M <= N the reference's plane rotations give R_jj = +norm
+// for every column that had something eliminated below it and det(Q) = +1, so
+//   qr_signfix flips column j of Q / row j of R where tau_j != 0 and R_jj < 0, and then, if the
+//   parity of (#reflectors + #flips) is odd, flips the last column of Q / last row of R.
+//
+// Per block column of width NB = 16 (work matrix W, reflectors kept explicitly in Vall):
+//   qr_panel   geqr2 + larft for rows [j0,M) x cols [j0,j0+nb) by ONE workgroup: 16 lanes own a
+//              row (one lane per panel column, coalesced 128-B rows), the panel stays in registers
+//              (<= 48 rows per lane group). Column norm = wave shuffle reduction + LDS across waves;
+//              the 16 dot products v^T [panel] of a step are reduced together (shuffle over the 4 row
+//              groups of a wave, LDS across the 16 waves) and give both the update of the columns to
+//              the right and the new column of T (V^T v).
+//   qr_vtc     Wp = V^T C for the trailing columns: fp64 MFMA 16x16x4 fed straight from global
+//              memory (both operands are "4 rows x 16 contiguous doubles" fragments), 256-row chunks
+//              combined through LDS, chunk partials summed in
+//   qr_tw      W2 = op(T) * sum_chunks(Wp)  (one thread per column)
+//   nd4_gemm   C -= V * W2 (gemm.hip, K = 16)
+// Q is formed by applying the block reflectors backwards to the identity with the same kernels.
 #include "nd4hip_internal.h"
-int nd4_geqrf_q(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*) {
-  nd4_set_error("nd4_geqrf_q: not implemented yet"); return ND4HIP_ERR_ARG;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NB = 16;
+constexpr int RMAX = 48;
+constexpr int VTC_ROWS = 256;     // rows per workgroup of qr_vtc
+constexpr int VTC_COLS = 64;      // columns per workgroup of qr_vtc
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------ panel
+// Slot i of lane group g is row j0 + g + 64*i; lane c of the group is column j0 + c.
+template <int R, bool REG>
+struct Slots {
+  double a[REG ? R : 1];
+  double* base;        // &W[j0+g][j0+c]
+  long step;           // 64 * ld
+  int nslots;          // rows in range for this group (GLOBAL mode bound)
+  bool col_ok;
+  int g, M, j0;
+  __device__ __forceinline__ int count() const { return REG ? R : nslots; }
+  __device__ __forceinline__ bool valid(int i) const { return col_ok && (j0 + g + 64 * i) < M; }
+  __device__ __forceinline__ double get(int i) const {
+    if constexpr (REG) return a[i];
+    else return valid(i) ? base[i * step] : 0.0;
+  }
+  __device__ __forceinline__ void set(int i, double v) {
+    if constexpr (REG) a[i] = v;
+    else if (valid(i)) base[i * step] = v;
+  }
+};
+
+template <int R, bool REG>
+__global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                   double* __restrict__ Vall, long ldv, long strideV,
+                                                   double* __restrict__ Tall, long strideT,
+                                                   double* __restrict__ taus, long strideTau, int j0, int nb) {
+  __shared__ double s_red[16];
+  __shared__ double s_w[16][NB];
+  __shared__ double s_T[NB][NB + 1];
+  __shared__ double s_Z[NB][NB];
+  __shared__ double s_tau[NB];
+  __shared__ double s_alpha;
+  double* A = Wm + blockIdx.x * strideW;
+  double* V = Vall + blockIdx.x * strideV;
+  const int t = threadIdx.x;
+  const int c = t & (NB - 1), g = t >> 4, wave = t >> 6;
+  const int klane_base = t & 48;
+
+  Slots<R, REG> S;
+  S.base = A + (long)(j0 + g) * ld + j0 + c; S.step = 64 * ld; S.col_ok = c < nb; S.g = g; S.M = M; S.j0 = j0;
+  S.nslots = (M - j0 - g + 63) / 64; if (S.nslots < 0) S.nslots = 0;
+  if constexpr (REG) {
+#pragma unroll
+    for (int i = 0; i < R; i++) S.a[i] = S.valid(i) ? S.base[i * S.step] : 0.0;
+  }
+  if (t < NB * (NB + 1)) (&s_T[0][0])[t] = 0.0;
+  __syncthreads();
+
+  for (int k = 0; k < nb; k++) {
+    // ---- 1. alpha = W[jc][jc], sigma = sum_{r > jc} W[r][jc]^2 (rows beyond M hold zeros) ----
+    double part = 0.0;
+    if (c == k) {
+      const double x0 = S.get(0);
+      if (g > k) part = x0 * x0;
+      if (g == k) s_alpha = x0;
+#pragma unroll
+      for (int i = 1; i < S.count(); i++) { const double x = S.get(i); part += x * x; }
+    }
+    part = wave_sum(part);
+    if ((t & 63) == 0) s_red[wave] = part;
+    __syncthreads();
+    double sigma = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) sigma += s_red[w];
+    const double alpha = s_alpha;
+    double beta = alpha, tau = 0.0, scale = 0.0;
+    if (sigma != 0.0) {
+      beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    // ---- 2. d_c = sum_r v_r * W[r][c]  (c > k: columns still to update; c < k: V_c^T v_k for T) ----
+    double d = 0.0;
+    {
+      const double x = S.get(0);
+      const double xk = __shfl(x, klane_base | k, 64);
+      const double vr = (g > k) ? xk * scale : ((g == k) ? 1.0 : 0.0);
+      d = vr * x;
+    }
+#pragma unroll
+    for (int i = 1; i < S.count(); i++) {
+      const double x = S.get(i);
+      const double vr = __shfl(x, klane_base | k, 64) * scale;
+      d += vr * x;
+    }
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    if ((t & 63) < NB) s_w[wave][c] = d;
+    __syncthreads();
+    double wc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) wc += s_w[w][c];
+    // ---- 3. apply H_k to the columns right of k, store v_k in column k ----
+    {
+      const double x = S.get(0);
+      const double xk = __shfl(x, klane_base | k, 64);
+      const double vr = (g > k) ? xk * scale : ((g == k) ? 1.0 : 0.0);
+      double y = x;
+      if (c > k) y = x - tau * vr * wc;
+      else if (c == k) y = (g > k) ? vr : ((g == k) ? beta : x);
+      S.set(0, y);
+    }
+#pragma unroll
+    for (int i = 1; i < S.count(); i++) {
+      const double x = S.get(i);
+      const double vr = __shfl(x, klane_base | k, 64) * scale;
+      double y = x;
+      if (c > k) y = x - tau * vr * wc;
+      else if (c == k) y = vr;
+      S.set(i, y);
+    }
+    // ---- 4. keep z_k = V[:,0:k]^T v_k and tau_k for T (built after the loop) ----
+    if (t < k) s_Z[k][t] = wc;          // lane t < 16 has c == t
+    if (t == 0) { s_tau[k] = tau; taus[blockIdx.x * strideTau + j0 + k] = tau; }
+    // no barrier needed here: the next iteration's LDS writes all sit behind its own barriers
+  }
+  __syncthreads();
+  // ---- T (larft, forward columnwise): T[i][i] = tau_i, T[i][k] = -tau_k * sum_{j=i}^{k-1} T[i][j] * z_k[j].
+  // Row i of T depends only on row i -> thread i builds its row alone.
+  if (t < nb) {
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) row[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (k == t) row[k] = s_tau[k];
+      else if (k > t && k < nb) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (j >= t && j < k) sum += row[j] * s_Z[k][j];
+        row[k] = -s_tau[k] * sum;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) s_T[t][k] = row[k];
+  }
+  __syncthreads();
+
+  // ---- write back: R part (upper triangle incl. diagonal) stays in W, V goes to Vall explicitly ----
+#pragma unroll
+  for (int i = 0; i < S.count(); i++) {
+    const int lr = g + 64 * i, r = j0 + lr;
+    if (r < M && c < nb) {
+      const double x = S.get(i);
+      double* w = A + (long)r * ld + j0 + c;
+      double* v = V + (long)r * ldv + j0 + c;
+      if (lr <= c) { *w = x; *v = (lr == c) ? 1.0 : 0.0; }
+      else { *w = 0.0; *v = x; }
+    }
+  }
+  if (t < NB * NB) {
+    const int i = t / NB, j = t % NB;
+    Tall[blockIdx.x * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------ V^T C
+// Wp[chunk][i][j] = sum_{r in chunk} V[r][i] * C[r][j]; V: m x 16 (ldv), C: m x n (ldc).
+// grid (ceil(n/64), ceil(m/256), batch), 256 threads: wave w takes rows chunk*256 + w*64 .. +64 and
+// all 4 column strips of 16; the 4 waves' tiles are summed through LDS.
+__global__ __launch_bounds__(256) void qr_vtc(const double* __restrict__ V, long ldv, long strideV,
+                                               const double* __restrict__ C, long ldc, long strideC,
+                                               int m, int n, double* __restrict__ Wp, long ldw, long strideChunk, long strideWb) {
+  __shared__ double s_acc[4][4][4][64];      // [wave][strip][reg][lane]
+  V += blockIdx.z * strideV; C += blockIdx.z * strideC; Wp += blockIdx.z * strideWb + blockIdx.y * strideChunk;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fx = lane & 15, fk = lane >> 4;
+  const int col0 = blockIdx.x * VTC_COLS;
+  const int row0 = blockIdx.y * VTC_ROWS + wave * 64;
+  d4 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < 16; kk++) {
+    const int r = row0 + kk * 4 + fk;
+    const bool rok = r < m;
+    const double a = rok ? V[(long)r * ldv + fx] : 0.0;
+    double b[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int col = col0 + s * 16 + fx;
+      b[s] = (rok && col < n) ? C[(long)r * ldc + col] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], acc[s], 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s_acc[wave][s][r][lane] = acc[s][r];
+  __syncthreads();
+  // thread t -> (strip s = wave, lane): sums the four waves' copies, fixed order
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const double v = ((s_acc[0][wave][r][lane] + s_acc[1][wave][r][lane]) + s_acc[2][wave][r][lane]) + s_acc[3][wave][r][lane];
+    const int i = fk + 4 * r, col = col0 + wave * 16 + fx;
+    if (col < n) Wp[(long)i * ldw + col] = v;
+  }
+}
+
+// W2[:, j] = op(T) * sum_chunks Wp[chunk][:, j]; T upper triangular 16x16; trans -> T^T
+__global__ __launch_bounds__(256) void qr_tw(const double* __restrict__ Tall, long strideT, int panel, int trans,
+                                              const double* __restrict__ Wp, long ldw, long strideChunk, long strideWb, int nchunks,
+                                              int n, double* __restrict__ W2, long strideW2) {
+  __shared__ double s_T[NB][NB + 1];
+  const double* T = Tall + blockIdx.y * strideT + (long)panel * NB * NB;
+  Wp += blockIdx.y * strideWb; W2 += blockIdx.y * strideW2;
+  const int t = threadIdx.x;
+  s_T[t / NB][t % NB] = T[t];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + t;
+  if (col >= n) return;
+  double w[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) w[i] = 0.0;
+  for (int ch = 0; ch < nchunks; ch++)
+#pragma unroll
+    for (int i = 0; i < NB; i++) w[i] += Wp[ch * strideChunk + (long)i * ldw + col];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    double s = 0.0;
+    if (trans) {
+#pragma unroll
+      for (int j = 0; j < NB; j++) if (j <= i) s += s_T[j][i] * w[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; j++) if (j >= i) s += s_T[i][j] * w[j];
+    }
+    W2[(long)i * ldw + col] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ sign fix
+// One thread per matrix: decides the flips (reference convention, see file header).
+__global__ void qr_flips(const double* __restrict__ Rm, long ldr, long strideR, const double* __restrict__ taus, long strideTau,
+                         int M, int N, int L, int* __restrict__ flips, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double* R = Rm + b * strideR; const double* tau = taus + b * strideTau; int* f = flips + (long)b * L;
+  int parity = 0;
+  for (int j = 0; j < L; j++) {
+    int fl = 0;
+    if (tau[j] != 0.0) { parity ^= 1; if (R[(long)j * ldr + j] < 0.0) { fl = 1; parity ^= 1; } }
+    f[j] = fl;
+  }
+  // plane rotations never change the determinant: det(Q) = +1 whenever Q is square (M <= N)
+  if (M <= N && parity) f[L - 1] ^= 1;
+}
+// scale rows of R (rows x cols, ld) by -1 where flips[row]
+__global__ void qr_flip_rows(double* __restrict__ X, long ld, long strideX, int rows, int cols, const int* __restrict__ flips, int L) {
+  X += blockIdx.z * strideX; flips += (long)blockIdx.z * L;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y)
+    if (flips[r]) X[(long)r * ld + col] = -X[(long)r * ld + col];
+}
+// scale columns of Q (rows x cols, ld) by -1 where flips[col]
+__global__ void qr_flip_cols(double* __restrict__ X, long ld, long strideX, int rows, int cols, const int* __restrict__ flips, int L) {
+  X += blockIdx.z * strideX; flips += (long)blockIdx.z * L;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols || !flips[col]) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) X[(long)r * ld + col] = -X[(long)r * ld + col];
+}
+
+template <int R, bool REG>
+void launch_panel(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
+                  double* T, long sT, double* taus, long sTau, int j0, int nb) {
+  hipLaunchKernelGGL((qr_panel<R, REG>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+}
+
+struct QrWs {
+  double *V, *T, *taus, *Wp, *W2, *work; int* flips;
+  long ldv, sV, sT, sTau, ldw, sChunk, sWb, sW2;
+  int nchunks_max;
+};
+
+// C (rows [j0,M) x n columns starting at C0) <- (I - V op(T) V^T) C, V = Vall[j0:, j0:j0+nb]
+int apply_block_reflector(nd4hip_handle* h, const QrWs& ws, int batch, int M, int j0, int panel, int trans,
+                          double* C0, long ldc, long strideC, int n) {
+  if (n <= 0) return 0;
+  const int m = M - j0;
+  const int nchunks = (m + VTC_ROWS - 1) / VTC_ROWS;
+  const double* Vp = ws.V + (long)j0 * ws.ldv + j0;
+  hipLaunchKernelGGL(qr_vtc, dim3((unsigned)((n + VTC_COLS - 1) / VTC_COLS), (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
+                     Vp, ws.ldv, ws.sV, C0, ldc, strideC, m, n, ws.Wp, ws.ldw, ws.sChunk, ws.sWb);
+  hipLaunchKernelGGL(qr_tw, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                     ws.T, ws.sT, panel, trans, ws.Wp, ws.ldw, ws.sChunk, ws.sWb, nchunks, n, ws.W2, ws.sW2);
+  ND4_HIP(hipGetLastError());
+  return nd4_gemm(h, false, false, m, n, NB, -1.0, Vp, ws.ldv, ws.sV, ws.W2, ws.ldw, ws.sW2, 1.0, C0, ldc, strideC, batch);
+}
+
+}  // namespace
+
+int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A, double* Q, double* R) {
+  ND4_CHECK_ARG(M64 < (1ll << 30) && N64 < (1ll << 30) && batch64 < 65536, "nd4_geqrf_q: extent out of range");
+  const int M = (int)M64, N = (int)N64, batch = (int)batch64;
+  const int L = M < N ? M : N;
+  const int npanels = (L + NB - 1) / NB;
+  const bool tall = M > N;
+
+  // ---- workspace carve-up (all per-matrix blocks are multiples of 2 doubles -> 16-B aligned) ----
+  QrWs ws;
+  ws.ldv = ((L + NB - 1) / NB) * NB;                        // Vall: M x ldv, zero above each panel
+  ws.sV = (long)M * ws.ldv;
+  ws.sT = (long)npanels * NB * NB;
+  ws.sTau = ws.ldv;
+  const int ncols = (N > L ? N : L);
+  ws.ldw = ((ncols + 1) / 2) * 2;
+  ws.nchunks_max = (M + VTC_ROWS - 1) / VTC_ROWS;
+  ws.sChunk = (long)NB * ws.ldw;
+  ws.sWb = ws.sChunk * ws.nchunks_max;
+  ws.sW2 = ws.sChunk;
+  const long sWork = tall ? (long)M * N : 0;
+  size_t doubles = (size_t)batch * (ws.sV + ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
+  size_t bytes = doubles * sizeof(double) + (size_t)batch * L * sizeof(int) + 64;
+  void* p = nullptr;
+  ND4_TRY(nd4_workspace(h, bytes, &p));
+  double* d = static_cast<double*>(p);
+  ws.V = d; d += (size_t)batch * ws.sV;
+  ws.T = d; d += (size_t)batch * ws.sT;
+  ws.taus = d; d += (size_t)batch * ws.sTau;
+  ws.Wp = d; d += (size_t)batch * ws.sWb;
+  ws.W2 = d; d += (size_t)batch * ws.sW2;
+  ws.work = tall ? d : nullptr; d += (size_t)batch * sWork;
+  ws.flips = reinterpret_cast<int*>(d);
+
+  // working matrix: R's buffer when it has A's shape (M <= N), a workspace copy when tall
+  double* W = tall ? ws.work : R;
+  const long ld = N, sW = (long)M * N;
+  ND4_HIP(hipMemcpyAsync(W, A, sizeof(double) * batch * sW, hipMemcpyDeviceToDevice, h->stream));
+  ND4_HIP(hipMemsetAsync(ws.V, 0, sizeof(double) * (size_t)batch * ws.sV, h->stream));
+
+  // ---- factorisation: panels left to right ----
+  for (int pnl = 0; pnl < npanels; pnl++) {
+    const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
+    const int Rn = (m + 63) / 64;
+    if (Rn <= 4)        launch_panel<4, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (Rn <= 8)   launch_panel<8, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (Rn <= 16)  launch_panel<16, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (Rn <= 32)  launch_panel<32, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (Rn <= RMAX) launch_panel<RMAX, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    ND4_HIP(hipGetLastError());
+    // trailing columns: C <- H^T C = (I - V T^T V^T) C
+    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + nb, ld, sW, N - j0 - nb));
+  }
+
+  // ---- R out (tall: top N x N of the work matrix; else already in place, lower part zeroed by the panels) ----
+  if (tall) ND4_TRY(nd4_copy_matrix(h, L, N, W, ld, R, N, batch, sW, (long)L * N));
+
+  // ---- Q = H_0 H_1 ... H_{p-1} [I; 0]: block reflectors applied backwards ----
+  const long sQ = (long)M * L;
+  ND4_TRY(nd4_set_identity(h, M, L, Q, L, batch, sQ));
+  for (int pnl = npanels - 1; pnl >= 0; pnl--) {
+    const int j0 = pnl * NB;
+    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/0, Q + (long)j0 * L + j0, L, sQ, L - j0));
+  }
+
+  // ---- reference sign convention ----
+  hipLaunchKernelGGL(qr_flips, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream,
+                     R, (long)N, (long)L * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
+  {
+    const unsigned gy = (unsigned)(L < 512 ? L : 512);
+    hipLaunchKernelGGL(qr_flip_rows, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream,
+                       R, (long)N, (long)L * N, L, N, ws.flips, L);
+    const unsigned gq = (unsigned)(M < 512 ? M : 512);
+    hipLaunchKernelGGL(qr_flip_cols, dim3((unsigned)((L + 255) / 256), gq, (unsigned)batch), dim3(256), 0, h->stream,
+                       Q, (long)L, sQ, M, L, ws.flips, L);
+  }
+  ND4_HIP(hipGetLastError());
+  return 0;
 }

@@ -1,0 +1,111 @@
+"""GPU parity of qr_decomp through the C ABI.
+
+The GPU runs blocked Householder; the reference runs Givens. What must agree is the OUTPUT: with
+the reference's sign convention restored (R_jj >= 0 where something was eliminated, det Q = +1 for
+M <= N) Q and R are unique for full-rank input, so values are compared norm-wise (gate 1e-10,
+asserted 1e-12). Degenerate inputs (zero rows/columns, rank deficient) have no unique factors:
+for them the reference's own test properties are checked (qr_test.js:149-187)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_cases
+from families import make_input
+from nd4js_amd import rng
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(x, ref):
+    return np.linalg.norm((x - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def la():
+    from nd4js_amd import la as _la
+    return _la
+
+
+def check_properties(a, q, r):
+    M, N = a.shape[-2:]
+    L = min(M, N)
+    assert q.shape == a.shape[:-2] + (M, L) and r.shape == a.shape[:-2] + (L, N)
+    assert np.array_equal(r, np.triu(r)), "R must be exactly upper triangular"
+    scale = max(np.abs(a).max(), 1e-300)
+    assert np.abs(q @ r - a).max() <= 1e-13 * max(M, N) * scale
+    eye = np.eye(L)
+    assert np.abs(np.swapaxes(q, -1, -2) @ q - eye).max() <= 1e-13 * max(M, 8)
+    if M <= N:
+        assert np.abs(q @ np.swapaxes(q, -1, -2) - np.eye(M)).max() <= 1e-13 * max(M, 8)
+        det = np.linalg.det(q)
+        assert np.allclose(det, 1.0, atol=1e-9), det           # plane rotations: det(Q) = +1
+
+
+UNIQUE = ("dense", "sparse10")
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases(op="qr_decomp") if not c.startswith("c3_")])
+def test_golden(la, golden, name):
+    g = golden(name)
+    a = make_input(g.seed, g.shape, g.family)
+    q, r = la.qr_decomp(a)
+    check_properties(a, q, r)
+    M, N = a.shape[-2:]
+    if g.family in UNIQUE and M <= N:
+        assert relerr(r, g["R"]) <= 1e-12 and relerr(q, g["Q"]) <= 1e-12
+    if g.family in ("diag", "triu"):
+        # nothing to eliminate: the reference returns Q = I, R = A (signs untouched)
+        assert np.array_equal(r, g["R"]) and np.array_equal(q, g["Q"])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (3, 5), (15, 15), (16, 16), (17, 17), (33, 47), (64, 64), (100, 100),
+                                   (129, 200), (255, 255), (256, 256), (257, 300), (500, 500), (1000, 1000)])
+def test_vs_oracle_square_and_wide(la, shape):
+    a = rng.matrix(900 + shape[0], *shape)
+    q, r = la.qr_decomp(a)
+    rq, rr = oracle.qr_decomp(a)
+    check_properties(a, q, r)
+    assert relerr(r, rr) <= 1e-12 and relerr(q, rq) <= 1e-12
+
+
+@pytest.mark.parametrize("shape", [(5, 3), (40, 17), (300, 64), (1000, 130)])
+def test_tall_properties(la, shape):
+    a = rng.matrix(950 + shape[0], *shape)
+    q, r = la.qr_decomp(a)
+    check_properties(a, q, r)
+    # |R| is unique for full column rank even where the sign convention of the tall branch differs
+    _, rr = oracle.qr_decomp(a)
+    assert relerr(np.abs(r), np.abs(rr)) <= 1e-12
+
+
+def test_batched(la):
+    a = rng.matrix(960, 3, 4, 37, 37)
+    q, r = la.qr_decomp(a)
+    rq, rr = oracle.qr_decomp(a)
+    check_properties(a, q, r)
+    assert relerr(r, rr) <= 1e-12 and relerr(q, rq) <= 1e-12
+
+
+def test_negative_determinant_goes_to_last_diagonal(la):
+    a = rng.matrix(961, 30, 30)
+    a[[0, 1]] = a[[1, 0]]                     # flips the sign of det(A)
+    for x in (a, rng.matrix(961, 30, 30)):
+        q, r = la.qr_decomp(x)
+        d = np.diag(r)
+        assert np.all(d[:-1] > 0)
+        assert np.sign(d[-1]) == np.sign(np.linalg.det(x))
+
+
+def test_c3_2048_against_reference(la, golden):
+    g = golden("c3_qr2048")
+    N = g.shape[-1]
+    a = rng.matrix(g.seed, N, N)
+    q, r = la.qr_decomp(a)
+    assert relerr(np.diag(r), g["diagR"]) <= 1e-11
+    for x, key in ((q, "Q"), (r, "R")):
+        got, val = x.reshape(-1)[g[key + "idx"]], g[key + "val"]
+        assert np.linalg.norm(got - val) / np.linalg.norm(val) <= 1e-11
+    assert abs(np.linalg.norm(r) - g.froR) <= 1e-11 * g.froR
+    assert abs(np.linalg.norm(q) - g.froQ) <= 1e-11 * g.froQ
+    assert np.abs(q @ r - a).max() <= 1e-11
+    assert np.abs(q.T @ q - np.eye(N)).max() <= 1e-12
