@@ -239,7 +239,8 @@ int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, dou
   const long total = (long)batch * N;
   hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, N, total);
   void* ws = nullptr;
-  ND4_TRY(nd4_workspace(h, sizeof(int32_t) * total, &ws));
+  Nd4WsScope scope(h);
+  ND4_TRY(nd4_ws_alloc(h, sizeof(int32_t) * total, &ws));
   int32_t* ipiv = static_cast<int32_t*>(ws);
 
   for (int j0 = 0; j0 < N; j0 += NB) {

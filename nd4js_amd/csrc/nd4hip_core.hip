@@ -49,7 +49,7 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-  if (h->ws) (void)hipFree(h->ws);
+  for (auto& b : h->ws) (void)hipFree(b.p);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -73,16 +73,42 @@ extern "C" int nd4hip_synchronize(nd4hip_handle* h) {
   return 0;
 }
 
-int nd4_workspace(nd4hip_handle* h, size_t bytes, void** out) {
-  if (bytes > h->ws_bytes) {
-    ND4_HIP(hipStreamSynchronize(h->stream));          // nothing may still use the old block
-    if (h->ws) { ND4_HIP(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
-    size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-    ND4_HIP(hipMalloc(&h->ws, want));
-    h->ws_bytes = want;
+int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~size_t(255);
+  if (bytes == 0) bytes = 256;
+  // first fit in the LAST block only (LIFO discipline keeps release trivial)
+  if (!h->ws.empty()) {
+    Nd4WsBlock& b = h->ws.back();
+    if (b.size - b.used >= bytes) { *out = b.p + b.used; b.used += bytes; return 0; }
   }
-  *out = h->ws;
+  // nothing in use anywhere and nothing fits: drop the cached blocks instead of piling up new ones
+  bool idle = true;
+  for (auto& b : h->ws) idle = idle && b.used == 0;
+  if (idle && !h->ws.empty()) {
+    for (auto& b : h->ws) if (b.size >= bytes) { std::swap(b, h->ws.back()); h->ws.back().used = bytes; *out = h->ws.back().p; return 0; }
+    ND4_HIP(hipStreamSynchronize(h->stream));
+    for (auto& b : h->ws) (void)hipFree(b.p);
+    h->ws.clear();
+  }
+  size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess && want != bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
+  if (e != hipSuccess) return nd4_hip_fail(e, "hipMalloc(workspace)", __FILE__, __LINE__);
+  h->ws.push_back(Nd4WsBlock{static_cast<char*>(p), want, bytes});
+  *out = p;
   return 0;
+}
+Nd4WsScope::Nd4WsScope(nd4hip_handle* hh) : h(hh), nblocks(hh->ws.size()), used_last(hh->ws.empty() ? 0 : hh->ws.back().used) {}
+Nd4WsScope::~Nd4WsScope() {
+  if (h->ws.size() < nblocks) {            // the idle arena was rebuilt inside this (top-level) scope
+    for (auto& b : h->ws) b.used = 0;
+    return;
+  }
+  // blocks opened inside the scope become empty (kept for reuse); the block that was last at entry
+  // returns to its old fill level
+  for (size_t i = nblocks; i < h->ws.size(); i++) h->ws[i].used = 0;
+  if (nblocks > 0) h->ws[nblocks - 1].used = used_last;
 }
 int nd4_pinned(nd4hip_handle* h, size_t bytes, void** out) {
   if (bytes > h->pinned_bytes) {

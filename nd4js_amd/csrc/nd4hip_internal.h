@@ -4,14 +4,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <vector>
 #include "../../include/nd4hip.h"
+
+struct Nd4WsBlock { char* p; size_t size, used; };
 
 struct nd4hip_handle {
   int device = 0;
   hipStream_t own_stream = nullptr;   // created by nd4hip_create
   hipStream_t stream = nullptr;       // the stream work is enqueued on (own or caller's)
-  void* ws = nullptr;                 // growable device workspace
-  size_t ws_bytes = 0;
+  std::vector<Nd4WsBlock> ws;         // device workspace arena (bump allocation, LIFO release)
   void* pinned = nullptr;             // small pinned host buffer for scalar read-backs
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -28,8 +30,15 @@ int  nd4_hip_fail(hipError_t e, const char* what, const char* file, int line);
   do { if (!(cond)) { nd4_set_error(__VA_ARGS__); return ND4HIP_ERR_ARG; } } while (0)
 #define ND4_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
 
-// workspace: returns a device pointer valid until the next nd4_workspace call with a larger size
-int nd4_workspace(nd4hip_handle* h, size_t bytes, void** out);
+// Workspace arena. Kernels are stream-ordered, so a region released at the end of one call can be
+// handed out to the next call on the same stream. Nested users (SVD -> QR -> GEMM) each open a
+// Nd4WsScope; allocations never move or free blocks that are in use.
+int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out);      // 256-byte aligned
+struct Nd4WsScope {
+  nd4hip_handle* h; size_t nblocks; size_t used_last;
+  explicit Nd4WsScope(nd4hip_handle* hh);
+  ~Nd4WsScope();
+};
 int nd4_pinned(nd4hip_handle* h, size_t bytes, void** out);
 
 // ---- internal launchers (device pointers, enqueue on h->stream) --------------------------------

@@ -355,7 +355,8 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   size_t doubles = (size_t)batch * (ws.sV + ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
   size_t bytes = doubles * sizeof(double) + (size_t)batch * L * sizeof(int) + 64;
   void* p = nullptr;
-  ND4_TRY(nd4_workspace(h, bytes, &p));
+  Nd4WsScope scope(h);
+  ND4_TRY(nd4_ws_alloc(h, bytes, &p));
   double* d = static_cast<double*>(p);
   ws.V = d; d += (size_t)batch * ws.sV;
   ws.T = d; d += (size_t)batch * ws.sT;

@@ -1,4 +1,328 @@
+// One-sided (Hestenes) Jacobi SVD on the ROWS of row-major fp64 matrices, batched.
+//
+// Output contract of src/la/svd.js:25 (svd_decomp = svd_dc, svd_dc.js:883-932): A = U diag(sv) V,
+// sv >= 0 sorted descending, V rows = right singular vectors. The reference's own Jacobi relatives
+// (svd_jac_2sided.js:95-134, _svd_jac_utils.js:123-188) define the stopping rule and the
+// post-processing that are mirrored here:
+//   * rotate rows p,q iff |a_p.a_q| > N*eps*|a_p||a_q|  (one-sided form of svd_jac_2sided.js:112);
+//     stop after a sweep without rotations (:95-97);
+//   * epilogue = _svd_jac_post: sv from the work matrix, non-negative, sorted descending with the
+//     same permutation applied to U^T rows and V rows, U transposed at the end.
+// W = Ut * A is iterated (Ut = accumulated left rotations, starts as I): at convergence the rows of W
+// are orthogonal, sv_i = |w_i|, V_i = w_i / sv_i, U = Ut^T. Rows are contiguous -> every access is
+// coalesced. Pairs follow a round-robin tournament: N/2 disjoint pairs per step, N-1 steps per sweep,
+// one workgroup per pair; the three inner products use wave shuffle reductions.
+// Rectangular input is reduced to square by QR first (svd_jac_2sided.js:42-52 does the same).
 #include "nd4hip_internal.h"
-int nd4_gesvdj(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*, int*, double*) {
-  nd4_set_error("nd4_gesvdj: not implemented yet"); return ND4HIP_ERR_ARG;
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+
+namespace {
+
+constexpr int MAX_SWEEPS = 60;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+struct JacState {            // per-matrix device state
+  unsigned rotations;        // rotations applied in the current sweep
+  unsigned done;             // converged in an earlier sweep
+};
+
+// round-robin pairing: n2 players (even), step s in [0, n2-1), slot i in [0, n2/2)
+__device__ __forceinline__ void rr_pair(int n2, int s, int i, int& p, int& q) {
+  const int m = n2 - 1;
+  if (i == 0) { p = m; q = s; }
+  else { p = (s + i) % m; q = (s - i + m) % m; }
+  if (p > q) { const int t = p; p = q; q = t; }
+}
+
+__global__ __launch_bounds__(256) void jac_step(double* __restrict__ Wm, double* __restrict__ Utm, int N, long strideM,
+                                                 int n2, int step, double tol2, JacState* __restrict__ st,
+                                                 const double* __restrict__ floor2, unsigned long long* __restrict__ offmax) {
+  const int mat = blockIdx.y;
+  if (st[mat].done) return;
+  int p, q;
+  rr_pair(n2, step, blockIdx.x, p, q);
+  if (q >= N) return;                                  // dummy player of an odd N
+  double* wp = Wm + mat * strideM + (long)p * N;
+  double* wq = Wm + mat * strideM + (long)q * N;
+  const int t = threadIdx.x;
+  double aa = 0.0, bb = 0.0, ab = 0.0;
+  for (int j = t; j < N; j += 256) {
+    const double a = wp[j], b = wq[j];
+    aa += a * a; bb += b * b; ab += a * b;
+  }
+  __shared__ double s_red[4][3];
+  aa = wave_sum(aa); bb = wave_sum(bb); ab = wave_sum(ab);
+  if ((t & 63) == 0) { s_red[t >> 6][0] = aa; s_red[t >> 6][1] = bb; s_red[t >> 6][2] = ab; }
+  __syncthreads();
+  aa = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+  bb = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+  ab = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+  // rows at or below the noise floor N*eps*max|a_i| carry no information (a rotation only swaps
+  // rounding noise): they are frozen here and get an orthonormal completion in the epilogue
+  const double fl = floor2[mat];
+  if (aa <= fl || bb <= fl) return;
+  const double lim = tol2 * aa * bb;
+  if (!(ab * ab > lim)) return;                        // orthogonal enough (also: NaN)
+  // rotation that zeroes the inner product: t^2 + 2*zeta*t - 1 = 0, smaller root
+  const double zeta = (bb - aa) / (2.0 * ab);
+  const double tn = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
+  for (int j = t; j < N; j += 256) {
+    const double a = wp[j], b = wq[j];
+    wp[j] = c * a - s * b;
+    wq[j] = s * a + c * b;
+  }
+  double* up = Utm + mat * strideM + (long)p * N;
+  double* uq = Utm + mat * strideM + (long)q * N;
+  for (int j = t; j < N; j += 256) {
+    const double a = up[j], b = uq[j];
+    up[j] = c * a - s * b;
+    uq[j] = s * a + c * b;
+  }
+  if (t == 0) {
+    atomicAdd(&st[mat].rotations, 1u);
+    const double rel = (ab * ab) / (aa * bb);          // cos^2 of the angle before the rotation
+    atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
+  }
+}
+
+// floor2[mat] = (N*eps)^2 * max_i |w_i|^2 ; one workgroup per matrix
+__global__ __launch_bounds__(256) void jac_floor(const double* __restrict__ Wm, int N, long strideM, double tol2, double* __restrict__ floor2) {
+  const double* W = Wm + blockIdx.x * strideM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double mx = 0.0;
+  for (int r = wave; r < N; r += 4) {
+    double s = 0.0;
+    for (int j = lane; j < N; j += 64) { const double x = W[(long)r * N + j]; s += x * x; }
+    s = wave_sum(s);
+    mx = fmax(mx, s);
+  }
+  __shared__ double s_mx[4];
+  if (lane == 0) s_mx[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) floor2[blockIdx.x] = tol2 * fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+}
+
+__global__ void jac_sweep_end(JacState* __restrict__ st, int batch, unsigned* __restrict__ active) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= batch) return;
+  if (!st[m].done) {
+    if (st[m].rotations == 0) st[m].done = 1; else atomicAdd(active, 1u);
+    st[m].rotations = 0;
+  }
+}
+
+// sv_raw[i] = |w_i| : one wave per row
+__global__ __launch_bounds__(256) void jac_norms(const double* __restrict__ Wm, int N, long strideM, double* __restrict__ svr) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const double* w = Wm + blockIdx.y * strideM + (long)row * N;
+  double s = 0.0;
+  for (int j = lane; j < N; j += 64) s += w[j] * w[j];
+  s = wave_sum(s);
+  if (lane == 0) svr[(long)blockIdx.y * N + row] = sqrt(s);
+}
+
+// rank[i] = position of row i in the descending order (stable: ties keep ascending index)
+__global__ void jac_rank(const double* __restrict__ svr, int N, int* __restrict__ rank) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double* s = svr + (long)blockIdx.y * N;
+  const double si = s[i];
+  int r = 0;
+  for (int j = 0; j < N; j++) { const double sj = s[j]; r += (sj > si || (sj == si && j < i)) ? 1 : 0; }
+  rank[(long)blockIdx.y * N + i] = r;
+}
+
+// V[rank_i] = w_i / sv_i ; Utp[rank_i] = Ut[i] ; sv[rank_i] = sv_i
+__global__ __launch_bounds__(256) void jac_emit(const double* __restrict__ Wm, const double* __restrict__ Utm, int N, long strideM,
+                                                 const double* __restrict__ svr, const int* __restrict__ rank,
+                                                 double* __restrict__ V, double* __restrict__ Utp, double* __restrict__ sv) {
+  const int i = blockIdx.x, mat = blockIdx.y, t = threadIdx.x;
+  const int r = rank[(long)mat * N + i];
+  const double s = svr[(long)mat * N + i];
+  const double inv = s > 0.0 ? 1.0 / s : 0.0;
+  const double* w = Wm + mat * strideM + (long)i * N;
+  const double* u = Utm + mat * strideM + (long)i * N;
+  double* v = V + mat * strideM + (long)r * N;
+  double* o = Utp + mat * strideM + (long)r * N;
+  for (int j = t; j < N; j += 256) { v[j] = w[j] * inv; o[j] = u[j]; }
+  if (t == 0) sv[(long)mat * N + r] = s;
+}
+
+// Rows of V whose singular value is at or below the noise floor (sorted to the end) are replaced by an orthonormal
+// completion: pick the unit vector e_j with the largest residual against the rows above, orthogonalise
+// twice (classical Gram-Schmidt with re-orthogonalisation), normalise. One workgroup per matrix.
+__global__ __launch_bounds__(1024) void jac_complete(double* __restrict__ Vm, int N, long strideM, const double* __restrict__ svm,
+                                                      const double* __restrict__ floor2, double* __restrict__ scratch) {
+  double* V = Vm + blockIdx.x * strideM;
+  const double* sv = svm + (long)blockIdx.x * N;
+  double* d = scratch + (long)blockIdx.x * N;
+  const int t = threadIdx.x, T = 1024, lane = t & 63, wave = t >> 6, nw = 16;
+  int z0 = N;
+  const double fl = floor2[blockIdx.x];
+  while (z0 > 0 && sv[z0 - 1] * sv[z0 - 1] <= fl) z0--;
+  if (z0 == N) return;
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_best;
+  __shared__ double s_norm;
+  for (int r = z0; r < N; r++) {
+    // candidate = column with the smallest sum of squares over rows < r
+    double best = DBL_MAX; int bidx = 0x7fffffff;
+    for (int j = t; j < N; j += T) {
+      double cn = 0.0;
+      for (int k = 0; k < r; k++) { const double x = V[(long)k * N + j]; cn += x * x; }
+      if (cn < best) { best = cn; bidx = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
+      if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+    __syncthreads();
+    if (t == 0) {
+      double b = s_val[0]; int bi = s_idx[0];
+      for (int w = 1; w < nw; w++) if (s_val[w] < b || (s_val[w] == b && s_idx[w] < bi)) { b = s_val[w]; bi = s_idx[w]; }
+      s_best = bi;
+    }
+    __syncthreads();
+    const int cand = s_best;
+    double* v = V + (long)r * N;
+    for (int j = t; j < N; j += T) v[j] = (j == cand) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+      for (int k = wave; k < r; k += nw) {
+        double s = 0.0;
+        for (int j = lane; j < N; j += 64) s += V[(long)k * N + j] * v[j];
+        s = wave_sum(s);
+        if (lane == 0) d[k] = s;
+      }
+      __syncthreads();
+      for (int j = t; j < N; j += T) {
+        double acc = v[j];
+        for (int k = 0; k < r; k++) acc -= d[k] * V[(long)k * N + j];
+        v[j] = acc;
+      }
+      __syncthreads();
+    }
+    double s = 0.0;
+    for (int j = t; j < N; j += T) s += v[j] * v[j];
+    s = wave_sum(s);
+    if (lane == 0) s_val[wave] = s;
+    __syncthreads();
+    if (t == 0) { double n = 0.0; for (int w = 0; w < nw; w++) n += s_val[w]; s_norm = sqrt(n); }
+    __syncthreads();
+    const double inv = 1.0 / s_norm;
+    for (int j = t; j < N; j += T) v[j] *= inv;
+    __syncthreads();
+  }
+}
+
+// W (N x N, batch) holds the input and is destroyed. Outputs U, sv, V (dense, N x N / N).
+int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, double* sv, double* V,
+                  int* sweeps_out, double* offnorm_out) {
+  Nd4WsScope scope(h);
+  const long sM = (long)N * N;
+  void* p = nullptr;
+  const size_t nd = (size_t)batch * (2 * sM + 2 * N + 1);
+  const size_t nrank = ((size_t)batch * N + 1) & ~size_t(1);          // keeps the 64-bit words behind it aligned
+  ND4_TRY(nd4_ws_alloc(h, nd * sizeof(double) + nrank * sizeof(int) + (size_t)batch * sizeof(JacState) + 64, &p));
+  double* Ut = static_cast<double*>(p);
+  double* Utp = Ut + (size_t)batch * sM;
+  double* svr = Utp + (size_t)batch * sM;
+  double* scratch = svr + (size_t)batch * N;
+  double* floor2 = scratch + (size_t)batch * N;
+  int* rank = reinterpret_cast<int*>(floor2 + batch);
+  JacState* st = reinterpret_cast<JacState*>(rank + nrank);
+  unsigned* active = reinterpret_cast<unsigned*>(st + batch);           // [1] + padding
+  unsigned long long* offmax = reinterpret_cast<unsigned long long*>(active + 2);
+  void* pin = nullptr;
+  ND4_TRY(nd4_pinned(h, 64, &pin));
+  unsigned* h_active = static_cast<unsigned*>(pin);
+  unsigned long long* h_off = reinterpret_cast<unsigned long long*>(h_active + 2);
+
+  ND4_TRY(nd4_set_identity(h, N, N, Ut, N, batch, sM));
+  ND4_HIP(hipMemsetAsync(st, 0, sizeof(JacState) * batch + 24, h->stream));
+
+  const int n2 = (N + 1) & ~1;
+  const double eps = 0x1p-52, tol = N * eps, tol2 = tol * tol;
+  hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, W, N, sM, tol2, floor2);
+  int sweeps = 0;
+  unsigned long long last_off = 0;
+  if (N > 1) {
+    for (;;) {
+      ND4_HIP(hipMemsetAsync(active, 0, 24, h->stream));            // active + offmax
+      for (int s = 0; s < n2 - 1; s++)
+        hipLaunchKernelGGL(jac_step, dim3((unsigned)(n2 / 2), (unsigned)batch), dim3(256), 0, h->stream,
+                           W, Ut, N, sM, n2, s, tol2, st, floor2, offmax);
+      hipLaunchKernelGGL(jac_sweep_end, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, st, batch, active);
+      ND4_HIP(hipGetLastError());
+      ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
+      ND4_HIP(hipStreamSynchronize(h->stream));
+      sweeps++;
+      if (h_active[0] == 0) { last_off = *h_off; break; }
+      last_off = *h_off;
+      if (sweeps >= MAX_SWEEPS) break;
+    }
+  }
+  // ---- epilogue (_svd_jac_post contract) ----
+  hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
+  hipLaunchKernelGGL(jac_rank, dim3((unsigned)((N + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, svr, N, rank);
+  hipLaunchKernelGGL(jac_emit, dim3((unsigned)N, (unsigned)batch), dim3(256), 0, h->stream, W, Ut, N, sM, svr, rank, V, Utp, sv);
+  hipLaunchKernelGGL(jac_complete, dim3((unsigned)batch), dim3(1024), 0, h->stream, V, N, sM, sv, floor2, scratch);
+  ND4_HIP(hipGetLastError());
+  ND4_TRY(nd4_transpose(h, N, N, Utp, N, U, N, batch, sM, sM));
+  if (sweeps_out) *sweeps_out = sweeps;
+  if (offnorm_out) { double r; unsigned long long b = last_off; memcpy(&r, &b, 8); *offnorm_out = sqrt(r); }
+  if (sweeps >= MAX_SWEEPS && N > 1) {
+    ND4_HIP(hipStreamSynchronize(h->stream));
+    nd4_set_error("nd4hip_dgesvdj: no convergence after %d sweeps", sweeps);
+    return ND4HIP_ERR_NOCONV;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int nd4_gesvdj(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A,
+               double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
+  ND4_CHECK_ARG(M64 < 46000 && N64 < 46000 && batch64 < 65536, "nd4_gesvdj: extent out of range");
+  const int M = (int)M64, N = (int)N64, batch = (int)batch64;
+  const int L = M < N ? M : N;
+  Nd4WsScope scope(h);
+  const long sL = (long)L * L;
+  void* p = nullptr;
+  if (M == N) {
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sL, &p));
+    double* W = static_cast<double*>(p);
+    ND4_HIP(hipMemcpyAsync(W, A, sizeof(double) * (size_t)batch * sL, hipMemcpyDeviceToDevice, h->stream));
+    return jacobi_square(h, batch, N, W, U, sv, V, sweeps_out, offnorm_out);
+  }
+  const long sA = (long)M * N;                 // also the size of the thin Q
+  if (M > N) {
+    // A = Q R ; R = Ur S V  ->  U = Q Ur                         (svd_jac_2sided.js:44-47)
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (sA + 2 * sL), &p));
+    double* Q = static_cast<double*>(p); double* R = Q + (size_t)batch * sA; double* Ur = R + (size_t)batch * sL;
+    ND4_TRY(nd4_geqrf_q(h, batch, M, N, A, Q, R));
+    ND4_TRY(jacobi_square(h, batch, N, R, Ur, sv, V, sweeps_out, offnorm_out));
+    return nd4_gemm(h, false, false, M, N, N, 1.0, Q, N, sA, Ur, N, sL, 0.0, U, N, sA, batch);
+  }
+  // M < N:  A^T = Q R  ->  A = R^T Q^T ; R^T = U S Vr  ->  V = Vr Q^T   (svd_jac_2sided.js:48-52)
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (2 * sA + 3 * sL), &p));
+  double* At = static_cast<double*>(p); double* Q = At + (size_t)batch * sA;
+  double* R = Q + (size_t)batch * sA; double* Rt = R + (size_t)batch * sL; double* Vr = Rt + (size_t)batch * sL;
+  ND4_TRY(nd4_transpose(h, M, N, A, N, At, M, batch, sA, sA));
+  ND4_TRY(nd4_geqrf_q(h, batch, N, M, At, Q, R));
+  ND4_TRY(nd4_transpose(h, M, M, R, M, Rt, M, batch, sL, sL));
+  ND4_TRY(jacobi_square(h, batch, M, Rt, U, sv, Vr, sweeps_out, offnorm_out));
+  return nd4_gemm(h, false, true, M, N, M, 1.0, Vr, M, sL, Q, M, sA, 0.0, V, N, sA, batch);
 }
