@@ -1,0 +1,111 @@
+"""Side measurements that ride along in bench.py's JSON line ("ops"): the other BASELINE configs.
+
+  lu2048 / qr2048 / svd2048   one 2048^2 matrix on ONE GPU (replicas only: single matrices do not shard)
+  svd_batch                   BASELINE configs[4]: batch x (512x512) SVDs, batch axis sharded over the
+                              ranks (contiguous blocks), no data-path collective; afterwards a health
+                              all-reduce (max sweeps / max off-norm) and the all-gather of sv over RCCL.
+Flop conventions: SURVEY.md §8(d) (LU 2/3 N^3, QR with explicit Q 8/3 N^3, SVD nominal 21 N^3).
+"""
+import os
+import time
+
+import torch
+
+PEAK_FP64_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+
+def _time(fn, h, reps):
+    fn()                                   # warm-up (workspace allocation, code load)
+    torch.cuda.synchronize()
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    h.timer_start()
+    for _ in range(reps):
+        fn()
+    return h.timer_stop() / reps
+
+
+def shard(batch, world, rank):
+    """contiguous block of the batch axis owned by `rank`"""
+    per, rem = divmod(batch, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def run(world, rank, local, dist, svd_batch=None, n_single=2048):
+    from nd4js_amd import _lib, dev
+    h = _lib.handle(local)
+    out = {}
+    if world == 1:
+        N = n_single
+        A = dev.fill_uniform(7, (N, N))
+        ms = _time(lambda: dev.lu_decomp(A), h, 5)
+        f = 2.0 / 3.0 * N ** 3
+        out["lu%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                           "algorithmic_flops": f}
+        ms = _time(lambda: dev.qr_decomp(A), h, 5)
+        f = 8.0 / 3.0 * N ** 3
+        out["qr%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                           "algorithmic_flops": f}
+        A9 = dev.fill_uniform(9, (N, N))
+        info = {}
+        ms = _time(lambda: dev.svd_decomp(A9, info=info), h, 1)
+        f = 21.0 * N ** 3
+        sweeps = info.get("sweeps", 0)
+        out["svd%d" % N] = {"ms": round(ms, 2), "gflops_nominal": round(f / ms / 1e6, 1), "sweeps": sweeps,
+                            "jacobi_executed_gflops": round(7.0 * N * N * (N - 1) * sweeps / ms / 1e6, 1),
+                            "jacobi_sweep_traffic_GBps": round(32.0 * N * N * (N - 1) * sweeps / ms / 1e6, 1),
+                            "frac_hbm_peak": round(32.0 * N * N * (N - 1) * sweeps / ms / 1e6 / PEAK_HBM_GBS, 4),
+                            "offnorm": info.get("offnorm")}
+    # ---- batched SVD, batch axis sharded over ranks ----
+    B = int(os.environ.get("ND4_BENCH_SVD_BATCH", svd_batch or 1024))
+    n = 512
+    lo, hi = shard(B, world, rank)
+    mine = hi - lo
+    X = torch.empty((mine, n, n), dtype=torch.float64, device="cuda")
+    for k in range(mine):
+        _lib.check(h.lib.nd4hip_fill_uniform_dev(h.ptr, 1000 + lo + k, 0, n * n, X[k].data_ptr()))
+    info = {}
+    dev.svd_decomp(X[: min(mine, 8)], info=info)        # warm-up on a slice
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    U, sv, V = dev.svd_decomp(X, info=info)
+    health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(health, op=dist.ReduceOp.MAX)                 # R1: convergence/health
+        gathered = [torch.empty((shard(B, world, r)[1] - shard(B, world, r)[0], n), dtype=torch.float64, device="cuda") for r in range(world)]
+        dist.all_gather(gathered, sv)                                 # R2: singular values of the whole batch
+        sv_all = torch.cat(gathered)
+        dist.barrier()
+    else:
+        sv_all = sv
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    f = 21.0 * n ** 3 * B
+    res = {"batch": B, "n": n, "n_gpus": world, "seconds": round(dt, 4), "gflops_nominal": round(f / dt / 1e9, 1),
+           "matrices_per_s": round(B / dt, 1), "max_sweeps": int(health[0].item()), "max_offnorm": health[1].item(),
+           "scaling": "strong (fixed batch sharded over ranks)"}
+    if rank == 0:
+        # parity gate: members with golden sv (every 16th) against the reference
+        try:
+            import json
+            import numpy as np
+            root = os.path.dirname(os.path.abspath(__file__))
+            with open(os.path.join(root, "tests", "golden", "manifest.json")) as fh:
+                g = json.load(fh)["cases"].get("c5_svd512")
+            if g:
+                members = np.load(os.path.join(root, "tests", "golden", g["files"]["members"]))
+                ref = np.load(os.path.join(root, "tests", "golden", g["files"]["sv"]))
+                keep = members < B
+                got = sv_all[torch.from_numpy(members[keep].astype("int64")).cuda()].cpu().numpy()
+                res["sv_vs_reference_max_rel"] = float(np.abs(got - ref[keep]).max() / ref[keep].max())
+        except Exception as e:  # pragma: no cover
+            res["parity_error"] = repr(e)
+    out["svd_batch"] = res
+    return out

@@ -1,0 +1,236 @@
+'use strict';
+/* nd4hip — Node.js host side of the MI355X backend for nd4js's `nd.la` hot path.
+ *
+ * Same function names, argument meaning, result layout and error messages as the reference:
+ *   matmul2     src/la/matmul.js:91-147        qr_decomp   src/la/qr.js:80-145
+ *   matmul      src/la/matmul.js:150-236       lu_decomp   src/la/lu.js:24-81
+ *   svd_decomp  src/la/svd.js:25 (= svd_dc, src/la/svd_dc.js:883-932)
+ * Every float64 call goes through the N-API addon (nd4hip_napi.node -> libnd4hip.so -> HIP kernels).
+ * There is NO CPU implementation in this package. Two ways to use it:
+ *
+ *   const la = require('nd4js_amd/js');                 // standalone: minimal NDArray, float64 only
+ *   const nd = require('nd4js'); require('nd4js_amd/js').install(nd);
+ *        // drop-in: nd.la.{matmul2,matmul,qr_decomp,lu_decomp,svd_decomp,svd_dc} run on the GPU for
+ *        // float64 / int32(promoted) input; other dtypes (float32, complex128, object, int32 x int32
+ *        // matmul) keep going to nd4js's own functions, exactly as before.
+ */
+const path = require('path');
+let addon = null;
+function native() {
+  if (addon === null) {
+    try { addon = require(path.join(__dirname, 'nd4hip_napi.node')); }
+    catch (e) { throw new Error('nd4hip: cannot load the N-API addon (' + e.message + '). Build it with `python -m nd4js_amd.build`; there is no CPU fallback.'); }
+  }
+  return addon;
+}
+
+/* ---- minimal NDArray (src/nd_array.js:128-158): dense, row-major, shape Int32Array ---- */
+class NDArray {
+  constructor(shape, data) {
+    if (!(shape instanceof Int32Array)) throw new Error('Shape must be Int32Array.');
+    if (shape.some(s => s < 1)) throw new Error(`Invalid shape: ${shape}.`);
+    if (data.length !== shape.reduce((a, b) => a * b, 1)) throw new Error(`Shape [${shape}] does not match array length of ${data.length}.`);
+    this.shape = shape; this.data = data; Object.freeze(this.shape.buffer);
+  }
+  get ndim() { return this.shape.length; }
+  get dtype() {
+    if (this.data instanceof Float64Array) return 'float64';
+    if (this.data instanceof Float32Array) return 'float32';
+    if (this.data instanceof Int32Array) return 'int32';
+    return 'object';
+  }
+  get T() {   // transposes the last two axes (copy), like nd_array.js:362-366
+    const sh = Int32Array.from(this.shape), n = sh.length;
+    if (n < 2) return this;
+    const [M, N] = [sh[n - 2], sh[n - 1]]; sh[n - 2] = N; sh[n - 1] = M;
+    const out = new this.data.constructor(this.data.length);
+    for (let o = 0; o < out.length; o += M * N)
+      for (let i = 0; i < M; i++) for (let j = 0; j < N; j++) out[o + j * M + i] = this.data[o + i * N + j];
+    return new NDArray(sh, out);
+  }
+}
+function fromNested(a) {           // nested JS arrays -> NDArray(float64)  (asarray, nd_array.js:102-126)
+  const shape = [];
+  for (let x = a; Array.isArray(x); x = x[0]) shape.push(x.length);
+  const data = new Float64Array(shape.reduce((p, q) => p * q, 1));
+  let k = 0;
+  (function walk(x, d) {
+    if (d === shape.length) { data[k++] = +x; return; }
+    if (!Array.isArray(x) || x.length !== shape[d]) throw new Error('asarray(): ragged nested array.');
+    for (const y of x) walk(y, d + 1);
+  })(a, 0);
+  return new NDArray(Int32Array.from(shape.length ? shape : [1]), data);
+}
+function makeAsarray(NDA) {
+  return function asarray(a) {
+    if (a && a.shape instanceof Int32Array && a.data !== undefined) return a;     // NDArray of either package
+    if (Array.isArray(a)) { const r = fromNested(a); return NDA === NDArray ? r : new NDA(r.shape, r.data); }
+    if (typeof a === 'number') return new NDA(Int32Array.of(1), Float64Array.of(a));
+    throw new Error('asarray(): unsupported argument.');
+  };
+}
+const dtypeOf = a => a.data instanceof Float64Array ? 'float64' : a.data instanceof Int32Array ? 'int32' :
+  a.data instanceof Float32Array ? 'float32' : (a.dtype || 'object');
+const f64 = a => a.data instanceof Float64Array ? a.data : Float64Array.from(a.data);    // int32 -> float64 promotion
+const prod = (s, from, to) => { let p = 1; for (let i = from; i < to; i++) p *= s[i]; return p; };
+
+/* Flatten NumPy-style broadcasting of the leading axes into (count, offA, strideA, offB, strideB, offC)
+ * groups with batch strides in {0, dense}: the job of the odometer at matmul.js:44-70. */
+function bcastGroups(lead, la, lb, IK, KJ) {
+  const nb = lead.length, pad = (s) => Array(nb - s.length).fill(1).concat(Array.from(s));
+  la = pad(la); lb = pad(lb);
+  const strides = (sh, unit) => { const st = Array(nb).fill(0); let s = unit; for (let d = nb - 1; d >= 0; d--) { st[d] = sh[d] > 1 ? s : 0; s *= sh[d]; } return st; };
+  const stA = strides(la, IK), stB = strides(lb, KJ), total = lead.reduce((a, b) => a * b, 1);
+  const offA = new Float64Array(total), offB = new Float64Array(total), idx = Array(nb).fill(0);
+  for (let b = 0; b < total; b++) {
+    let a = 0, c = 0; for (let d = 0; d < nb; d++) { a += idx[d] * stA[d]; c += idx[d] * stB[d]; }
+    offA[b] = a; offB[b] = c;
+    for (let d = nb - 1; d >= 0; d--) { if (++idx[d] < lead[d]) break; idx[d] = 0; }
+  }
+  const groups = [];
+  for (let b0 = 0; b0 < total;) {
+    let b1 = b0 + 1, sA = 0, sB = 0;
+    if (b1 < total) {
+      sA = offA[b1] - offA[b0]; sB = offB[b1] - offB[b0];
+      if ((sA === 0 || sA === IK) && (sB === 0 || sB === KJ))
+        while (b1 < total && offA[b1] - offA[b1 - 1] === sA && offB[b1] - offB[b1 - 1] === sB) b1++;
+      else sA = sB = 0;
+    }
+    groups.push([b1 - b0, offA[b0], sA, offB[b0], sB, b0]);
+    b0 = b1;
+  }
+  return groups;
+}
+
+function makeLa(NDA, fallback) {
+  const asarray = makeAsarray(NDA);
+  const gpuOk = a => { const d = dtypeOf(a); return d === 'float64' || d === 'int32'; };
+  const la = {};
+
+  la.matmul2 = function matmul2(a, b) {
+    a = asarray(a); b = asarray(b);
+    if (a.ndim < 2) throw new Error('A must be at least 2D.');
+    if (b.ndim < 2) throw new Error('B must be at least 2D.');
+    const I = a.shape[a.ndim - 2], K = a.shape[a.ndim - 1], J = b.shape[b.ndim - 1];
+    if (b.shape[b.ndim - 2] != K) throw new Error('The last dimension of A and the 2nd to last dimension of B do not match.');
+    const da = dtypeOf(a), db = dtypeOf(b);
+    // GPU path: at least one float64 operand and the other float64/int32 (result dtype float64, matmul.js:119);
+    // int32 x int32 (wrapping Int32Array result), float32, complex128, object -> the host's own function
+    if (!((da === 'float64' && gpuOk(b)) || (db === 'float64' && gpuOk(a)))) {
+      if (fallback && fallback.matmul2) return fallback.matmul2(a, b);
+      throw new Error(`nd4hip.matmul2: dtype pair (${da}, ${db}) is not accelerated and no host nd4js was installed.`);
+    }
+    const ndim = Math.max(a.ndim, b.ndim), shape = Int32Array.from({length: ndim}, () => 1);
+    shape[ndim - 2] = I; shape[ndim - 1] = J;
+    for (const arr of [a, b])
+      for (let i = ndim - 2, j = arr.ndim - 2; i-- > 0 && j-- > 0;)
+        if (1 === shape[i]) shape[i] = arr.shape[j];
+        else if (shape[i] != arr.shape[j] && arr.shape[j] != 1) throw new Error('Shapes are not broadcast-compatible.');
+    const lead = Array.from(shape.subarray(0, ndim - 2));
+    const A = f64(a), B = f64(b), C = new Float64Array(shape.reduce((m, n) => m * n, 1));
+    for (const [cnt, offA, sA, offB, sB, offC] of bcastGroups(lead, a.shape.subarray(0, a.ndim - 2), b.shape.subarray(0, b.ndim - 2), I * K, K * J))
+      native().dgemm_batched(cnt, I, K, J, A.subarray(offA), sA, B.subarray(offB), sB, C.subarray(offC * I * J));
+    return new NDA(shape, C);
+  };
+
+  la.matmul = function matmul(...matrices) {            // chain ordering stays on the host (matmul.js:150-236)
+    matrices = matrices.map(asarray);
+    if (matrices.length == 1) return matrices[0];
+    if (matrices.length == 2) return la.matmul2(...matrices);
+    const nOps = (sA, sB) => {
+      const I = sA[sA.length - 2], K = sA[sA.length - 1], J = sB[sB.length - 1];
+      if (sB[sB.length - 2] != K) throw new Error('Shape mismatch.');
+      const ndim = Math.max(sA.length, sB.length), shape = Int32Array.from({length: ndim}, () => 1);
+      shape[ndim - 2] = I; shape[ndim - 1] = J;
+      for (const shp of [sA, sB])
+        for (let i = ndim - 2, j = shp.length - 2; i-- > 0 && j-- > 0;)
+          if (1 === shape[i]) shape[i] = shp[j];
+          else if (shape[i] != shp[j] && shp[j] != 1) throw new Error('Shapes are not broadcast-compatible.');
+      return [shape.reduce((x, y) => x * y, 1) * K, shape];
+    };
+    const n = matrices.length, op = Array.from({length: n}, () => []);
+    for (let i = 0; i < n; i++) op[i][i] = [0, matrices[i].shape];
+    for (let len = 2; len <= n; len++)
+      for (let i = 0; i <= n - len; i++) {
+        let minF = Infinity, minS;
+        for (let j = 1; j < len; j++) {
+          const [lf, ls] = op[i][i + j - 1], [rf, rs] = op[i + j][i + len - 1];
+          let [f, s] = nOps(ls, rs); f += lf + rf;
+          if (f < minF) { minF = f; minS = s; }
+        }
+        if (minS === undefined) throw new Error('Integer overflow (too many FLOPs).');
+        op[i][i + len - 1] = [minF, minS];
+      }
+    const product = (from, to) => {
+      if (from == to) return matrices[from];
+      let minF = Infinity, minI;
+      for (let i = from; i < to; i++) {
+        const f = nOps(op[from][i][1], op[i + 1][to][1])[0] + op[from][i][0] + op[i + 1][to][0];
+        if (f < minF) { minF = f; minI = i; }
+      }
+      return la.matmul2(product(from, minI), product(minI + 1, to));
+    };
+    return product(0, n - 1);
+  };
+
+  la.qr_decomp = function qr_decomp(A) {
+    A = asarray(A);
+    if (A.ndim < 2) throw new Error('qr_decomp(A): A.ndim must be at least 2.');
+    if (!gpuOk(A)) { if (fallback && fallback.qr_decomp) return fallback.qr_decomp(A); throw new Error('nd4hip.qr_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], L = Math.min(M, N), batch = prod(A.shape, 0, nd_ - 2);
+    const Qs = Int32Array.from(A.shape), Rs = Int32Array.from(A.shape); Qs[nd_ - 1] = L; Rs[nd_ - 2] = L;
+    const Q = new Float64Array(batch * M * L), R = new Float64Array(batch * L * N);
+    native().dgeqrf_q_batched(batch, M, N, f64(A), Q, R);
+    return [new NDA(Qs, Q), new NDA(Rs, R)];
+  };
+
+  la.lu_decomp = function lu_decomp(A) {
+    A = asarray(A);
+    const nd_ = A.ndim;
+    if (nd_ < 2 || A.shape[nd_ - 2] != A.shape[nd_ - 1]) throw new Error('Last two dimensions must be quadratic.');
+    if (!gpuOk(A)) { if (fallback && fallback.lu_decomp) return fallback.lu_decomp(A); throw new Error('nd4hip.lu_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const N = A.shape[nd_ - 1], batch = prod(A.shape, 0, nd_ - 2);
+    const LU = new Float64Array(batch * N * N), P = new Int32Array(batch * N);
+    native().dgetrf_batched(batch, N, f64(A), LU, P);
+    return [new NDA(Int32Array.from(A.shape), LU), new NDA(Int32Array.from(A.shape.subarray(0, nd_ - 1)), P)];
+  };
+
+  la.svd_decomp = function svd_decomp(A) {
+    A = asarray(A);
+    if (String(dtypeOf(A)).startsWith('complex')) throw new Error('svd_dc(A): A.dtype must be float.');
+    if (A.ndim < 2) throw new Error('svd_decomp(A): A.ndim must be at least 2.');
+    if (!gpuOk(A)) { if (fallback && fallback.svd_decomp) return fallback.svd_decomp(A); throw new Error('nd4hip.svd_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], L = Math.min(M, N), batch = prod(A.shape, 0, nd_ - 2);
+    const Us = Int32Array.from(A.shape), Vs = Int32Array.from(A.shape); Us[nd_ - 1] = L; Vs[nd_ - 2] = L;
+    const U = new Float64Array(batch * M * L), sv = new Float64Array(batch * L), V = new Float64Array(batch * L * N);
+    la.last_svd_info = native().dgesvdj_batched(batch, M, N, f64(A), U, sv, V);
+    return [new NDA(Us, U), new NDA(Int32Array.from(Us.subarray(0, nd_ - 1)), sv), new NDA(Vs, V)];
+  };
+  la.svd_dc = la.svd_decomp;
+  return la;
+}
+
+const standalone = makeLa(NDArray, null);
+
+/** Patch a loaded nd4js instance in place: the five hot-path functions run on the GPU. Returns nd. */
+function install(nd) {
+  if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
+  const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp,
+                    lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc};
+  const acc = makeLa(nd.NDArray, original);
+  const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
+  const patched = target || Object.create(nd.la);
+  for (const k of Object.keys(original)) Object.defineProperty(patched, k, {value: acc[k], writable: true, enumerable: true, configurable: true});
+  if (!target) { try { nd.la = patched; } catch (e) { /* exported getter: caller uses the returned object */ } }
+  patched.__nd4hip_original__ = original;
+  if (target) return nd;
+  const out = Object.create(nd);
+  Object.defineProperty(out, 'la', {value: patched, enumerable: true, writable: true, configurable: true});
+  return out;
+}
+
+module.exports = Object.assign({}, standalone, {
+  NDArray, install, bcastGroups,
+  device_count: () => native().device_count(),
+  version: () => native().version(),
+});

@@ -1,0 +1,79 @@
+'use strict';
+/* Node-side checks of the JS host wrapper + N-API addon. Driven by tests/test_node_addon.py.
+ *   node node_checks.js cpu              (no GPU: validation, error text, loud failure)
+ *   node node_checks.js gpu <golden dir> (GPU: results vs the reference-generated golden vectors)
+ *   node node_checks.js install <path to reference dist/nd.js>   (drop-in patching, build container only)
+ */
+const fs = require('fs'), path = require('path');
+const la = require(path.join(__dirname, '..', '..', 'nd4js_amd', 'js'));
+const assert = require('assert');
+const mode = process.argv[2];
+
+function fmix32(h) { h ^= h >>> 16; h = Math.imul(h, 0x85ebca6b); h ^= h >>> 13; h = Math.imul(h, 0xc2b2ae35); h ^= h >>> 16; return h >>> 0; }
+function uniform(seed, idx) {
+  const hi = fmix32((idx ^ fmix32(seed >>> 0)) >>> 0), lo = fmix32((hi + 0x9E3779B9 + idx) >>> 0);
+  return ((hi >>> 5) * 67108864 + (lo >>> 6)) * 2.220446049250313e-16 - 1.0;
+}
+function fill(seed, shape) {
+  const n = shape.reduce((a, b) => a * b, 1), d = new Float64Array(n);
+  for (let i = 0; i < n; i++) d[i] = uniform(seed, i);
+  return new la.NDArray(Int32Array.from(shape), d);
+}
+function loadNpy(file) {
+  const buf = fs.readFileSync(file), hlen = buf.readUInt16LE(8), hdr = buf.toString('latin1', 10, 10 + hlen);
+  const descr = /'descr': '([^']+)'/.exec(hdr)[1];
+  const shape = /'shape': \(([^)]*)\)/.exec(hdr)[1].split(',').map(s => s.trim()).filter(s => s).map(Number);
+  const body = buf.slice(10 + hlen), ab = body.buffer.slice(body.byteOffset, body.byteOffset + body.byteLength);
+  return {shape, data: descr === '<f8' ? new Float64Array(ab) : new Int32Array(ab)};
+}
+function relerr(x, ref) { let n = 0, d = 0; for (let i = 0; i < ref.length; i++) { d += (x[i] - ref[i]) ** 2; n += ref[i] ** 2; } return Math.sqrt(d / Math.max(n, 1e-300)); }
+
+if (mode === 'cpu') {
+  assert.throws(() => la.matmul2([1, 2, 3], [[1], [2], [3]]), /A must be at least 2D\./);
+  assert.throws(() => la.matmul2([[1, 2, 3]], [1, 2, 3]), /B must be at least 2D\./);
+  assert.throws(() => la.matmul2([[1, 2, 3]], [[1, 2], [3, 4]]), /do not match/);
+  assert.throws(() => la.matmul2(fill(1, [2, 2, 3]), fill(2, [3, 3, 2])), /broadcast-compatible/);
+  assert.throws(() => la.qr_decomp([1, 2, 3]), /at least 2/);
+  assert.throws(() => la.lu_decomp([[1, 2, 3], [4, 5, 6]]), /quadratic/);
+  const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
+  assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
+  assert.ok(/gfx950/.test(la.version()));
+  if (la.device_count() === 0) {
+    for (const f of [() => la.matmul2(fill(1, [4, 4]), fill(2, [4, 4])), () => la.qr_decomp(fill(1, [4, 4])),
+                     () => la.lu_decomp(fill(1, [4, 4])), () => la.svd_decomp(fill(1, [4, 4]))])
+      assert.throws(f, /no HIP device/);          // loud failure, no CPU fallback
+  }
+  console.log('node cpu checks ok');
+}
+
+if (mode === 'install') {
+  const nd = require(process.argv[3]);
+  const nd2 = la.install(nd);
+  const a = new nd.NDArray(Int32Array.of(2, 2), Int32Array.of(1, 2, 3, 4));
+  const c = nd2.la.matmul2(a, a);                  // int32 x int32 keeps going to the reference's own code
+  assert.ok(c.data instanceof Int32Array && Array.from(c.data).join() === '7,10,15,22');
+  assert.strictEqual(typeof nd2.la.det, 'function'); // everything else is still there
+  if (la.device_count() === 0)
+    assert.throws(() => nd2.la.matmul2(new nd.NDArray(Int32Array.of(2, 2), Float64Array.of(1, 2, 3, 4)), a), /no HIP device/);
+  console.log('node install checks ok');
+}
+
+if (mode === 'gpu') {
+  const dir = process.argv[3], man = JSON.parse(fs.readFileSync(path.join(dir, 'manifest.json'))).cases;
+  const npy = (c, k) => loadNpy(path.join(dir, man[c].files[k]));
+  { const m = man.c1_matmul64, C = la.matmul2(fill(m.seedA, m.shapeA), fill(m.seedB, m.shapeB));
+    assert.ok(relerr(C.data, npy('c1_matmul64', 'C').data) <= 1e-13); }
+  { const m = man.bc_matmul_a, C = la.matmul2(fill(m.seedA, m.shapeA), fill(m.seedB, m.shapeB));
+    assert.deepStrictEqual(Array.from(C.shape), m.shapeC); assert.ok(relerr(C.data, npy('bc_matmul_a', 'C').data) <= 1e-13); }
+  { const m = man.c1_qr32, [Q, R] = la.qr_decomp(fill(m.seed, m.shape));
+    assert.ok(relerr(Q.data, npy('c1_qr32', 'Q').data) <= 1e-12 && relerr(R.data, npy('c1_qr32', 'R').data) <= 1e-12); }
+  { const m = man.mid_lu96, [LU, P] = la.lu_decomp(fill(m.seed, m.shape));
+    assert.deepStrictEqual(Array.from(P.data), Array.from(npy('mid_lu96', 'P').data));
+    assert.ok(P.data instanceof Int32Array && relerr(LU.data, npy('mid_lu96', 'LU').data) <= 1e-12); }
+  { const m = man.mid_svd96, [U, sv, V] = la.svd_decomp(fill(m.seed, m.shape)), ref = npy('mid_svd96', 'sv').data;
+    let d = 0; for (let i = 0; i < ref.length; i++) d = Math.max(d, Math.abs(sv.data[i] - ref[i]));
+    assert.ok(d <= 1e-12 * ref[0]); assert.deepStrictEqual(Array.from(U.shape), [96, 96]); assert.deepStrictEqual(Array.from(V.shape), [96, 96]);
+    assert.ok(la.last_svd_info.sweeps > 0); }
+  { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
+  console.log('node gpu checks ok');
+}

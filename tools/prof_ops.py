@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Profiling driver: runs selected hot-path ops a few times so that
+`rocprofv3 --kernel-trace --stats -- python3 tools/prof_ops.py lu qr` gives per-kernel times.
+usage: prof_ops.py [matmul] [lu] [qr] [svd] [svdbatch] [--n N] [--reps R]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from nd4js_amd import dev  # noqa: E402
+
+
+def main():
+    args = sys.argv[1:]
+    n = int(args[args.index("--n") + 1]) if "--n" in args else 2048
+    reps = int(args[args.index("--reps") + 1]) if "--reps" in args else 3
+    A = dev.fill_uniform(7, (n, n))
+    for _ in range(reps):
+        if "matmul" in args:
+            dev.matmul2(A, A)
+        if "lu" in args:
+            dev.lu_decomp(A)
+        if "qr" in args:
+            dev.qr_decomp(A)
+        if "svd" in args:
+            dev.svd_decomp(A)
+        if "svdbatch" in args:
+            X = dev.fill_uniform(1000, (32, 512, 512))
+            dev.svd_decomp(X)
+    torch.cuda.synchronize()
+    print("done", args)
+
+
+if __name__ == "__main__":
+    main()
