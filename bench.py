@@ -109,6 +109,19 @@ def main():
                          "kernel": "dgemm_kernel<NN,vec>", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 24.0 * n * n},
         }
+        # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of this same command
+        # (tools/pmc_summary.py -> profiles/; a profiler cannot wrap itself inside the timed run)
+        try:
+            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r"))
+            for rnd in reversed(pmc):
+                f = os.path.join(ROOT, "profiles", rnd, "gemm4096_pmc.json")
+                if os.path.exists(f) and n == 4096:
+                    with open(f) as fh:
+                        out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/%s/gemm4096_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)" % rnd
+                    break
+        except Exception:  # pragma: no cover
+            pass
         # parity gate printed with the number
         try:
             import numpy as np
@@ -124,7 +137,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 import numpy as np
-                cb, c_cpu = cpu_baseline_matmul(n, min(512, n))
+                cb, c_cpu = cpu_baseline_matmul(n, min(2048, n))
                 out["cpu_baseline"] = cb
                 out.setdefault("parity", {})["matmul_vs_oracle_rows_relerr"] = float(
                     np.linalg.norm(C[: c_cpu.shape[0]].cpu().numpy() - c_cpu) / np.linalg.norm(c_cpu))

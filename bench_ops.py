@@ -25,11 +25,7 @@ def _time(fn, h, reps):
     return h.timer_stop() / reps
 
 
-def shard(batch, world, rank):
-    """contiguous block of the batch axis owned by `rank`"""
-    per, rem = divmod(batch, world)
-    lo = rank * per + min(rank, rem)
-    return lo, lo + per + (1 if rank < rem else 0)
+from nd4js_amd.dist import shard  # noqa: E402  contiguous block of the batch axis owned by a rank
 
 
 def run(world, rank, local, dist, svd_batch=None, n_single=2048):
@@ -71,16 +67,11 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    U, sv, V = dev.svd_decomp(X, info=info)
-    health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0)], dtype=torch.float64, device="cuda")
+    from nd4js_amd.dist import svd_decomp_sharded
+    U, sv_all, V, hl = svd_decomp_sharded(X, B)         # local SVDs + R1 health all-reduce + R2 sv all-gather
+    health = torch.tensor([float(hl["max_sweeps"]), hl["max_offnorm"]], dtype=torch.float64)
     if dist is not None:
-        dist.all_reduce(health, op=dist.ReduceOp.MAX)                 # R1: convergence/health
-        gathered = [torch.empty((shard(B, world, r)[1] - shard(B, world, r)[0], n), dtype=torch.float64, device="cuda") for r in range(world)]
-        dist.all_gather(gathered, sv)                                 # R2: singular values of the whole batch
-        sv_all = torch.cat(gathered)
         dist.barrier()
-    else:
-        sv_all = sv
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -1,0 +1,60 @@
+"""Multi-GPU form of the batched decompositions: one process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI), the reference's leading batch axis (qr.js:43-49, lu.js:34-40,
+svd_dc.js:918-925 loop over independent matrices) cut into contiguous blocks, one per rank.
+
+There is NO data-path collective: matrices never interact. The only exchanges are
+  R1  all-reduce(MAX) of [sweeps, off-norm, failed]      (convergence / health, 24 bytes)
+  R2  all-gather of the singular values                   (batch x L doubles in total)
+Single matrices do not shard ("replicas only").
+"""
+import torch
+
+
+def shard(batch, world, rank):
+    """[lo, hi) of the batch axis owned by `rank`: contiguous blocks, remainder to the low ranks."""
+    per, rem = divmod(int(batch), int(world))
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def shard_sizes(batch, world):
+    return [shard(batch, world, r)[1] - shard(batch, world, r)[0] for r in range(world)]
+
+
+def svd_decomp_sharded(A_local, batch_total, group=None, compute=None):
+    """A_local: this rank's block [b_local, M, N] (device tensor). Returns (U_local, sv_all, V_local, health)
+    where sv_all is the [batch_total, L] result gathered on every rank and health = dict(max_sweeps,
+    max_offnorm, failed) reduced over all ranks. `compute` defaults to the GPU path."""
+    import torch.distributed as dist
+    if compute is None:
+        from . import dev
+        compute = dev.svd_decomp
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard(batch_total, world, rank)
+    assert A_local.shape[0] == hi - lo, "A_local must be this rank's contiguous block of the batch"
+    info, failed = {}, 0.0
+    try:
+        U, sv, V = compute(A_local, info=info)
+    except Exception:
+        failed = 1.0
+        raise
+    finally:
+        health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0), failed],
+                              dtype=torch.float64, device=A_local.device)
+        if world > 1:
+            dist.all_reduce(health, op=dist.ReduceOp.MAX, group=group)               # R1
+    if world > 1:
+        # equal-size exchange (blocks differ by at most one matrix): pad to the largest block, gather
+        # into one flat buffer (one collective, fully-connected over xGMI), trim the padding
+        L = sv.shape[-1]
+        sizes = shard_sizes(batch_total, world)
+        pad = max(sizes)
+        mine = torch.zeros((pad, L), dtype=sv.dtype, device=sv.device)
+        mine[: sv.shape[0]] = sv
+        buf = torch.empty((world * pad, L), dtype=sv.dtype, device=sv.device)
+        dist.all_gather_into_tensor(buf, mine, group=group)                           # R2
+        sv_all = torch.cat([buf[r * pad: r * pad + sizes[r]] for r in range(world)])
+    else:
+        sv_all = sv
+    return U, sv_all, V, {"max_sweeps": int(health[0].item()), "max_offnorm": health[1].item(), "failed": bool(health[2].item())}

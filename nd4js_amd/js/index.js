@@ -229,8 +229,9 @@ function install(nd) {
   return out;
 }
 
-module.exports = Object.assign({}, standalone, {
+module.exports = Object.assign(standalone, {
   NDArray, install, bcastGroups,
+  accelerated: a => !!a && (a.data instanceof Float64Array || a.data instanceof Int32Array),
   device_count: () => native().device_count(),
   version: () => native().version(),
 });
