@@ -13,10 +13,11 @@
 // coalesced. Pairs follow a round-robin tournament: N/2 disjoint pairs per step, N-1 steps per sweep,
 // one workgroup per pair; the three inner products use wave shuffle reductions.
 // Rectangular input is reduced to square by QR first (svd_jac_2sided.js:42-52 does the same).
-#include "nd4hip_internal.h"
+#include "svd_internal.h"
 #include <cmath>
 #include <cfloat>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -28,26 +29,13 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-struct JacState {            // per-matrix device state
-  unsigned rotations;        // rotations applied in the current sweep
-  unsigned done;             // converged in an earlier sweep
-};
-
-// round-robin pairing: n2 players (even), step s in [0, n2-1), slot i in [0, n2/2)
-__device__ __forceinline__ void rr_pair(int n2, int s, int i, int& p, int& q) {
-  const int m = n2 - 1;
-  if (i == 0) { p = m; q = s; }
-  else { p = (s + i) % m; q = (s - i + m) % m; }
-  if (p > q) { const int t = p; p = q; q = t; }
-}
-
 __global__ __launch_bounds__(256) void jac_step(double* __restrict__ Wm, double* __restrict__ Utm, int N, long strideM,
                                                  int n2, int step, double tol2, JacState* __restrict__ st,
                                                  const double* __restrict__ floor2, unsigned long long* __restrict__ offmax) {
   const int mat = blockIdx.y;
   if (st[mat].done) return;
   int p, q;
-  rr_pair(n2, step, blockIdx.x, p, q);
+  nd4_rr_pair(n2, step, blockIdx.x, p, q);
   if (q >= N) return;                                  // dummy player of an odd N
   double* wp = Wm + mat * strideM + (long)p * N;
   double* wq = Wm + mat * strideM + (long)q * N;
@@ -74,17 +62,21 @@ __global__ __launch_bounds__(256) void jac_step(double* __restrict__ Wm, double*
   const double zeta = (bb - aa) / (2.0 * ab);
   const double tn = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
   const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
+  // Rutishauser form with tau = tan(theta/2): x_p' = x_p - s (x_q + tau x_p), x_q' = x_q + s (x_p - tau x_q).
+  // 1 - c = s*tau is carried exactly, so the rotation stays orthogonal to O(eps * theta^2) even when c
+  // rounds to 1 (plain c*x - s*y grows every row norm by theta^2 per tiny rotation: a systematic drift).
+  const double tau = s / (1.0 + c);
   for (int j = t; j < N; j += 256) {
     const double a = wp[j], b = wq[j];
-    wp[j] = c * a - s * b;
-    wq[j] = s * a + c * b;
+    wp[j] = a - s * (b + tau * a);
+    wq[j] = b + s * (a - tau * b);
   }
   double* up = Utm + mat * strideM + (long)p * N;
   double* uq = Utm + mat * strideM + (long)q * N;
   for (int j = t; j < N; j += 256) {
     const double a = up[j], b = uq[j];
-    up[j] = c * a - s * b;
-    uq[j] = s * a + c * b;
+    up[j] = a - s * (b + tau * a);
+    uq[j] = b + s * (a - tau * b);
   }
   if (t == 0) {
     atomicAdd(&st[mat].rotations, 1u);
@@ -233,7 +225,9 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   Nd4WsScope scope(h);
   const long sM = (long)N * N;
   void* p = nullptr;
-  const size_t nd = (size_t)batch * (2 * sM + 2 * N + 1);
+  const bool blocked = (N % 64 == 0) && N >= 128 && !getenv("ND4HIP_SVD_NOBLOCK");          // block Jacobi on the matrix cores (svd_block.hip)
+  const size_t nblock = blocked ? nd4_jacobi_block_scratch_doubles(batch, N) : 0;
+  const size_t nd = (size_t)batch * (2 * sM + 2 * N + 1) + nblock;
   const size_t nrank = ((size_t)batch * N + 1) & ~size_t(1);          // keeps the 64-bit words behind it aligned
   ND4_TRY(nd4_ws_alloc(h, nd * sizeof(double) + nrank * sizeof(int) + (size_t)batch * sizeof(JacState) + 64, &p));
   double* Ut = static_cast<double*>(p);
@@ -241,7 +235,8 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   double* svr = Utp + (size_t)batch * sM;
   double* scratch = svr + (size_t)batch * N;
   double* floor2 = scratch + (size_t)batch * N;
-  int* rank = reinterpret_cast<int*>(floor2 + batch);
+  double* bscratch = floor2 + batch;
+  int* rank = reinterpret_cast<int*>(bscratch + nblock);
   JacState* st = reinterpret_cast<JacState*>(rank + nrank);
   unsigned* active = reinterpret_cast<unsigned*>(st + batch);           // [1] + padding
   unsigned long long* offmax = reinterpret_cast<unsigned long long*>(active + 2);
@@ -261,9 +256,13 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   if (N > 1) {
     for (;;) {
       ND4_HIP(hipMemsetAsync(active, 0, 24, h->stream));            // active + offmax
-      for (int s = 0; s < n2 - 1; s++)
-        hipLaunchKernelGGL(jac_step, dim3((unsigned)(n2 / 2), (unsigned)batch), dim3(256), 0, h->stream,
-                           W, Ut, N, sM, n2, s, tol2, st, floor2, offmax);
+      if (blocked) {
+        ND4_TRY(nd4_jacobi_block_sweep(h, batch, N, W, Ut, st, floor2, tol2, offmax, bscratch));
+      } else {
+        for (int s = 0; s < n2 - 1; s++)
+          hipLaunchKernelGGL(jac_step, dim3((unsigned)(n2 / 2), (unsigned)batch), dim3(256), 0, h->stream,
+                             W, Ut, N, sM, n2, s, tol2, st, floor2, offmax);
+      }
       hipLaunchKernelGGL(jac_sweep_end, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, st, batch, active);
       ND4_HIP(hipGetLastError());
       ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
