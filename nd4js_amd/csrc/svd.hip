@@ -85,21 +85,17 @@ __global__ __launch_bounds__(256) void jac_step(double* __restrict__ Wm, double*
   }
 }
 
-// floor2[mat] = (N*eps)^2 * max_i |w_i|^2 ; one workgroup per matrix
-__global__ __launch_bounds__(256) void jac_floor(const double* __restrict__ Wm, int N, long strideM, double tol2, double* __restrict__ floor2) {
-  const double* W = Wm + blockIdx.x * strideM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// floor2[mat] = (N*eps)^2 * max_i |w_i|^2 from the row norms (jac_norms); one workgroup per matrix
+__global__ __launch_bounds__(256) void jac_floor(const double* __restrict__ svr, int N, double tol2, double* __restrict__ floor2) {
+  const double* s = svr + (long)blockIdx.x * N;
   double mx = 0.0;
-  for (int r = wave; r < N; r += 4) {
-    double s = 0.0;
-    for (int j = lane; j < N; j += 64) { const double x = W[(long)r * N + j]; s += x * x; }
-    s = wave_sum(s);
-    mx = fmax(mx, s);
-  }
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmax(mx, s[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
   __shared__ double s_mx[4];
-  if (lane == 0) s_mx[wave] = mx;
+  if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) floor2[blockIdx.x] = tol2 * fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+  if (threadIdx.x == 0) { const double m = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])); floor2[blockIdx.x] = tol2 * m * m; }
 }
 
 __global__ void jac_sweep_end(JacState* __restrict__ st, int batch, unsigned* __restrict__ active) {
@@ -250,7 +246,8 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
 
   const int n2 = (N + 1) & ~1;
   const double eps = 0x1p-52, tol = N * eps, tol2 = tol * tol;
-  hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, W, N, sM, tol2, floor2);
+  hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
+  hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, svr, N, tol2, floor2);
   int sweeps = 0;
   unsigned long long last_off = 0;
   if (N > 1) {

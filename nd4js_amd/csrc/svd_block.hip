@@ -16,6 +16,7 @@
 //                update is in place.
 // Per sweep: 12 N^3 flop on MFMA and 40 N^3 / 32 bytes of traffic instead of 32 N^3 bytes.
 #include "svd_internal.h"
+#include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -25,7 +26,30 @@ namespace {
 constexpr int BB = 32;         // rows per block
 constexpr int PB = 64;         // rows per block pair
 constexpr int CH = 256;        // columns per workgroup (gram and apply)
-constexpr int MAX_INNER = 3;   // inner Jacobi sweeps per visit of a pair
+constexpr int MAX_INNER_DEFAULT = 1;   // inner Jacobi sweeps per visit of a pair (measured: the outer sweep count does not
+                                       // depend on it, 15-16 at N=2048 for 1, 2 and 4)
+
+// wave-uniform broadcast of lane K's value through SGPRs (v_readlane_b32): no LDS traffic, unlike __shfl
+template <int K> __device__ __forceinline__ int bcast_i(int v) { return __builtin_amdgcn_readlane(v, K); }
+template <int K> __device__ __forceinline__ double bcast_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), K), __builtin_amdgcn_readlane(__double2loint(v), K));
+}
+
+// few-ulp reciprocal / reciprocal square root: hardware estimate + two Newton steps. The Jacobi angle
+// only needs s and tau = s/(1+c) to be mutually consistent to a few ulp (orthogonality defect ~ theta^2 * ulp),
+// so IEEE-exact division (~35 dependent fp64 instructions each) is not worth its latency here.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
 
 __device__ __forceinline__ long pair_row(int x, int I, int J) { return x < BB ? (long)I * BB + x : (long)J * BB + (x - BB); }
 
@@ -46,7 +70,7 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
 #pragma unroll
   for (int j = 0; j < 4; j++) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
   const int col0 = chunk * CH;
-#pragma unroll 2
+#pragma unroll 8
   for (int k8 = 0; k8 < CH / 8; k8++) {
     const int c = col0 + k8 * 8 + 2 * fk;
     d2 f[4];
@@ -69,7 +93,7 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
 __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                                    JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
                                                    double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                   unsigned long long* __restrict__ offmax) {
+                                                   unsigned long long* __restrict__ offmax, int max_inner, int cross_only) {
   __shared__ double G[PB][PB + 1];
   __shared__ double Q[PB][PB + 1];
   __shared__ unsigned s_rot[4];
@@ -90,49 +114,70 @@ __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpa
   const double fl = floor2[mat];
   unsigned total = 0;
   double relmax = 0.0;
-  for (int inner = 0; inner < MAX_INNER; inner++) {
+  // converged pairs (the common case in the last sweeps) leave after one pass over the off-diagonal
+  {
+    int need = 0;
+    for (int e = t; e < PB * PB; e += 256) {
+      const int i = e / PB, j = e % PB;
+      if (i < j) { const double a = G[i][i], b = G[j][j], g = G[i][j]; need |= (a > fl) && (b > fl) && (g * g > tol2 * a * b); }
+    }
+    need = __syncthreads_or(need);
+    if (!need) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
+  }
+  // cross_only: the two blocks were orthogonalised internally on earlier visits of this sweep, so only the
+  // 32 x 32 pairs (p in I, q in J) are visited: 32 rounds of 32 disjoint pairs (i, 32 + (i + r) % 32).
+  const int nrounds = cross_only ? BB : PB - 1;
+  for (int inner = 0; inner < max_inner; inner++) {
     unsigned rot = 0;
-    for (int r = 0; r < PB - 1; r++) {
+    for (int r = 0; r < nrounds; r++) {
       int p, q;
-      nd4_rr_pair(PB, r, wave * 8 + (lane & 7), p, q);
+      if (cross_only) { p = wave * 8 + (lane & 7); q = BB + ((p + r) & (BB - 1)); }
+      else nd4_rr_pair(PB, r, wave * 8 + (lane & 7), p, q);
       const double a = G[p][p], b = G[q][q], g = G[p][q];
       const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
       double c = 1.0, s = 0.0;                              // kept as (s, tau = tan(theta/2)): see svd.hip jac_step
       if (go) {
-        const double zeta = (b - a) / (2.0 * g);
-        const double tn = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cc = 1.0 / sqrt(1.0 + tn * tn);
+        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (b-a)/(2g), rewritten without the division by g
+        const double d = b - a, hh = 2.0 * g, rr = d * d + hh * hh;
+        const double root = rr * fast_rsqrt(rr);
+        const double tn = (((d < 0.0) != (g < 0.0)) ? -fabs(hh) : fabs(hh)) * fast_rcp(fabs(d) + root);
+        const double cc = fast_rsqrt(1.0 + tn * tn);
         s = cc * tn;
-        c = s / (1.0 + cc);                                // c now holds tau
+        c = s * fast_rcp(1.0 + cc);                        // c now holds tau = tan(theta/2)
         relmax = fmax(relmax, (g * g) / (a * b));
       }
       rot += (unsigned)__popcll(__ballot(go && lane < 8));
-      // ---- row phase: rows p,q of G and of Q (lane = column) ----
+      // wave-uniform rotation parameters of this wave's 8 pairs (SGPRs)
+      double sk[8], ck[8]; int pk[8], qk[8];
+#define ND4_BC(K) sk[K] = bcast_d<K>(s); ck[K] = bcast_d<K>(c); pk[K] = bcast_i<K>(p); qk[K] = bcast_i<K>(q);
+      ND4_BC(0) ND4_BC(1) ND4_BC(2) ND4_BC(3) ND4_BC(4) ND4_BC(5) ND4_BC(6) ND4_BC(7)
+#undef ND4_BC
+      // ---- row phase: rows p,q of G and of Q (lane = column). The 8 pairs touch disjoint rows, so all
+      // 32 reads are issued before the first write (the compiler cannot prove that by itself and would
+      // serialise read->fma->write eight times: this loop is LDS-latency bound, not bandwidth bound).
+      // An idle pair (s = 0) rewrites its rows unchanged.
+      {
+        double gp[8], gq[8], up[8], uq[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const double sk = __shfl(s, k, 64);
-        if (sk != 0.0) {                                   // wave-uniform
-          const double ck = __shfl(c, k, 64);
-          const int pk = __shfl(p, k, 64), qk = __shfl(q, k, 64);
-          const double gp = G[pk][lane], gq = G[qk][lane];
-          G[pk][lane] = gp - sk * (gq + ck * gp);
-          G[qk][lane] = gq + sk * (gp - ck * gq);
-          const double up = Q[pk][lane], uq = Q[qk][lane];
-          Q[pk][lane] = up - sk * (uq + ck * up);
-          Q[qk][lane] = uq + sk * (up - ck * uq);
+        for (int k = 0; k < 8; k++) { gp[k] = G[pk[k]][lane]; gq[k] = G[qk[k]][lane]; up[k] = Q[pk[k]][lane]; uq[k] = Q[qk[k]][lane]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          G[pk[k]][lane] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
+          G[qk[k]][lane] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
+          Q[pk[k]][lane] = up[k] - sk[k] * (uq[k] + ck[k] * up[k]);
+          Q[qk[k]][lane] = uq[k] + sk[k] * (up[k] - ck[k] * uq[k]);
         }
       }
       __syncthreads();
       // ---- column phase: columns p,q of G (lane = row) ----
+      {
+        double gp[8], gq[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const double sk = __shfl(s, k, 64);
-        if (sk != 0.0) {
-          const double ck = __shfl(c, k, 64);
-          const int pk = __shfl(p, k, 64), qk = __shfl(q, k, 64);
-          const double gp = G[lane][pk], gq = G[lane][qk];
-          G[lane][pk] = gp - sk * (gq + ck * gp);
-          G[lane][qk] = gq + sk * (gp - ck * gq);
+        for (int k = 0; k < 8; k++) { gp[k] = G[lane][pk[k]]; gq[k] = G[lane][qk[k]]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          G[lane][pk[k]] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
+          G[lane][qk[k]] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
         }
       }
       __syncthreads();
@@ -213,11 +258,14 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   double* Qt = Gpart + (size_t)batch * sG;
   int* flags = reinterpret_cast<int*>(Qt + (size_t)batch * sQ);
   const long sF = ((npairs + 1) / 2 + 1) * 2;          // ints per matrix
+  static const int max_inner = getenv("ND4HIP_JAC_INNER") ? atoi(getenv("ND4HIP_JAC_INNER")) : MAX_INNER_DEFAULT;
+  static const int cross = getenv("ND4HIP_JAC_CROSS") ? atoi(getenv("ND4HIP_JAC_CROSS")) : 1;
   for (int step = 0; step < nblk2 - 1; step++) {
     hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                        W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
     hipLaunchKernelGGL(jacb_eigen, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
-                       Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax);
+                       Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
+                       (cross && step > 0) ? 1 : 0);
     hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
                        W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks);
   }
