@@ -95,6 +95,111 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
   }
 }
 
+// ---- thread-per-row panel kernel: each thread keeps R whole panel rows (16 doubles each) in registers ----
+// Row r = j0 + t + 512*i (512 threads: 256 VGPRs per lane hold up to 6 rows x 16 columns). Per column: ONE true division and 15-k FMAs per row, no cross-lane traffic in
+// the update; the arg-max is a wave shuffle reduction + 16 LDS partials that every thread finishes itself
+// (no second barrier); the pivot row and the displaced row travel through LDS. The k-loop is fully
+// unrolled so that every register index is static. 2 barriers per column.
+template <int R>
+__global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+  __shared__ PivCand s_red[8];
+  __shared__ double s_u[NB], s_j[NB];
+  double* A = LU + blockIdx.x * strideM;
+  int32_t* p = P + (long)blockIdx.x * N;
+  int32_t* ip = ipiv + (long)blockIdx.x * N;
+  const int t = threadIdx.x, wave = t >> 6;
+  double a[R][NB];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + 512 * i;
+#pragma unroll
+    for (int c = 0; c < NB; c++) a[i][c] = (r < N && c < nb) ? A[(long)r * N + j0 + c] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    if (k < nb) {                                        // uniform
+      const int jc = j0 + k;
+      // ---- arg-max of |column k| over rows >= jc ----
+      PivCand cand{-2.0, 0x7fffffff};
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 512 * i;
+        PivCand o{pivot_mag(a[i][k], r, jc), r};
+        if (r < jc || r >= N) o.mag = -2.0;
+        cand = better(cand, o);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        PivCand o;
+        o.mag = __shfl_xor(cand.mag, off);
+        o.idx = __shfl_xor(cand.idx, off);
+        cand = better(cand, o);
+      }
+      if ((t & 63) == 0) s_red[wave] = cand;
+      __syncthreads();
+      PivCand best = s_red[0];
+#pragma unroll
+      for (int w = 1; w < 8; w++) best = better(best, s_red[w]);
+      const int piv = best.idx;
+      if (t == 0) {
+        ip[jc] = piv;
+        if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
+      }
+      // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
+      const int pt = (piv - j0) & 511, pi = (piv - j0) >> 9;
+      if (t == pt) {
+#pragma unroll
+        for (int i = 0; i < R; i++)
+          if (i == pi) {
+#pragma unroll
+            for (int c = 0; c < NB; c++) s_u[c] = a[i][c];
+          }
+      }
+      if (t == k) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) s_j[c] = a[0][c];
+      }
+      __syncthreads();
+      if (piv != jc) {
+        if (t == pt) {
+#pragma unroll
+          for (int i = 0; i < R; i++)
+            if (i == pi) {
+#pragma unroll
+              for (int c = 0; c < NB; c++) a[i][c] = s_j[c];
+            }
+        }
+        if (t == k) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) a[0][c] = s_u[c];
+        }
+      }
+      // ---- eliminate below the pivot ----
+      const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 512 * i;
+        if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
+          const double l = a[i][k] / u[k];               // lu.js:68
+          a[i][k] = l;
+#pragma unroll
+          for (int c = k + 1; c < NB; c++) a[i][c] -= l * u[c];   // lu.js:71-72
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // keep the unrolled columns from interleaving (VGPR pressure)
+  }
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + 512 * i;
+    if (r < N) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (c < nb) A[(long)r * N + j0 + c] = a[i][c];
+    }
+  }
+}
+
 // ---- fast panel kernel: the panel (m <= 64*RMAX rows x 16 cols) lives in registers -------------
 // lane group g (16 lanes) owns rows j0 + g + 64*i; lane c of the group owns column j0 + c.
 template <int R>
@@ -225,6 +330,10 @@ __global__ void iota_kernel(int32_t* __restrict__ P, int N, long total) {
 }
 
 template <int R>
+void launch_panel_row(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch) {
+  hipLaunchKernelGGL((lu_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+}
+template <int R>
 void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch) {
   hipLaunchKernelGGL((lu_panel_reg<R>), dim3(batch), dim3(1024), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
 }
@@ -246,7 +355,11 @@ int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, dou
   for (int j0 = 0; j0 < N; j0 += NB) {
     const int nb = N - j0 < NB ? N - j0 : NB;
     const int m = N - j0;
-    if (m >= 256 && m <= 64 * RMAX) {
+    if (m >= 64 && m <= 2048) {
+      if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+    } else if (m > 2048 && m <= 64 * RMAX) {
       const int R = (m + 63) / 64;
       if (R <= 8)       launch_panel_reg<8>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
       else if (R <= 16) launch_panel_reg<16>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);

@@ -195,6 +195,151 @@ __global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M,
   }
 }
 
+// ---- thread-per-row panel kernel (m <= 2048): each of 512 threads keeps R whole panel rows in registers ----
+// Row r = j0 + t + 512*i. Per column k (fully unrolled -> static register indices, 2 barriers):
+//   sigma = sum_{r>jc} a[r][k]^2        wave shuffle reduction + 8 LDS partials
+//   d[c]  = sum_r v_r a[r][c], c=0..15  per-thread partials, then a HALVING butterfly: 8+4+2+1 shuffles leave
+//                                       one column total per lane (+2 to finish the wave), 8 LDS partials per
+//                                       column, and the 16 totals come back as wave-uniform readlane values
+//   update a[r][c>k] -= tau v_r d[c];  a[r][k] = v_r;  z_k = d[c<k] feeds T.
+template <int R>
+__global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                     double* __restrict__ Vall, long ldv, long strideV,
+                                                     double* __restrict__ Tall, long strideT,
+                                                     double* __restrict__ taus, long strideTau, int j0, int nb) {
+  __shared__ double s_red[8];
+  __shared__ double s_w[8][NB];
+  __shared__ double s_T[NB][NB + 1];
+  __shared__ double s_Z[NB][NB];
+  __shared__ double s_tau[NB];
+  __shared__ double s_alpha;
+  double* A = Wm + blockIdx.x * strideW;
+  double* V = Vall + blockIdx.x * strideV;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  const int mycol = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);   // column this lane ends up with
+
+  double a[R][NB];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + 512 * i;
+#pragma unroll
+    for (int c = 0; c < NB; c++) a[i][c] = (r < M && c < nb) ? A[(long)r * ld + j0 + c] : 0.0;
+  }
+  if (t < NB * (NB + 1)) (&s_T[0][0])[t] = 0.0;
+
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    if (k < nb) {
+      const int jc = j0 + k;
+      double part = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 512 * i;
+        if (r > jc) part += a[i][k] * a[i][k];
+      }
+      if (t == k) s_alpha = a[0][k];
+      part = wave_sum(part);
+      if (lane == 0) s_red[wave] = part;
+      __syncthreads();
+      double sigma = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) sigma += s_red[w];
+      const double alpha = s_alpha;
+      double beta = alpha, tau = 0.0, scale = 0.0;
+      if (sigma != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      double vr[R], d[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) d[c] = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 512 * i;
+        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+#pragma unroll
+        for (int c = 0; c < NB; c++) d[c] += vr[i] * a[i][c];
+      }
+      // halving butterfly over the 16 lanes of a group, then across the 4 groups of the wave
+      double e8[8], e4[4], e2[2], e1;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const double snd = b0 ? d[j] : d[j + 8], kp = b0 ? d[j + 8] : d[j]; e8[j] = kp + __shfl_xor(snd, 1); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const double snd = b1 ? e8[j] : e8[j + 4], kp = b1 ? e8[j + 4] : e8[j]; e4[j] = kp + __shfl_xor(snd, 2); }
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const double snd = b2 ? e4[j] : e4[j + 2], kp = b2 ? e4[j + 2] : e4[j]; e2[j] = kp + __shfl_xor(snd, 4); }
+      { const double snd = b3 ? e2[0] : e2[1], kp = b3 ? e2[1] : e2[0]; e1 = kp + __shfl_xor(snd, 8); }
+      e1 += __shfl_xor(e1, 16);
+      e1 += __shfl_xor(e1, 32);
+      if (lane < NB) s_w[wave][mycol] = e1;
+      __syncthreads();
+      double tot = 0.0;                                   // lane -> column lane & 15
+#pragma unroll
+      for (int w = 0; w < 8; w++) tot += s_w[w][lane & 15];
+      double wv[NB];                                      // wave-uniform totals
+#define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
+      ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3) ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7)
+      ND4_RL(8) ND4_RL(9) ND4_RL(10) ND4_RL(11) ND4_RL(12) ND4_RL(13) ND4_RL(14) ND4_RL(15)
+#undef ND4_RL
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 512 * i;
+        const double tv = tau * vr[i];
+#pragma unroll
+        for (int c = k + 1; c < NB; c++) a[i][c] -= tv * wv[c];
+        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < k) s_Z[k][c] = wv[c];
+        s_tau[k] = tau;
+        taus[blockIdx.x * strideTau + j0 + k] = tau;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  if (t < nb) {                                          // larft: row t of T depends only on row t
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) row[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (k == t) row[k] = s_tau[k];
+      else if (k > t && k < nb) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) if (j >= t && j < k) sum += row[j] * s_Z[k][j];
+        row[k] = -s_tau[k] * sum;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) s_T[t][k] = row[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int lr = t + 512 * i, r = j0 + lr;
+    if (r < M) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        if (c < nb) {
+          double* w = A + (long)r * ld + j0 + c;
+          double* v = V + (long)r * ldv + j0 + c;
+          if (lr <= c) { *w = a[i][c]; *v = (lr == c) ? 1.0 : 0.0; }
+          else { *w = 0.0; *v = a[i][c]; }
+        }
+      }
+    }
+  }
+  if (t < NB * NB) {
+    const int i = t / NB, j = t % NB;
+    Tall[blockIdx.x * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
+  }
+}
+
 // ------------------------------------------------------------------------------------ V^T C
 // Wp[chunk][i][j] = sum_{r in chunk} V[r][i] * C[r][j]; V: m x 16 (ldv), C: m x n (ldc).
 // grid (ceil(n/64), ceil(m/256), batch), 256 threads: wave w takes rows chunk*256 + w*64 .. +64 and
@@ -303,6 +448,11 @@ __global__ void qr_flip_cols(double* __restrict__ X, long ld, long strideX, int 
   for (int r = blockIdx.y; r < rows; r += gridDim.y) X[(long)r * ld + col] = -X[(long)r * ld + col];
 }
 
+template <int R>
+void launch_panel_row(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
+                      double* T, long sT, double* taus, long sTau, int j0, int nb) {
+  hipLaunchKernelGGL((qr_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+}
 template <int R, bool REG>
 void launch_panel(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
                   double* T, long sT, double* taus, long sTau, int j0, int nb) {
@@ -376,7 +526,10 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   for (int pnl = 0; pnl < npanels; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
     const int Rn = (m + 63) / 64;
-    if (Rn <= 4)        launch_panel<4, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    if (m <= 512)       launch_panel_row<1>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (m <= 1024) launch_panel_row<2>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (m <= 2048) launch_panel_row<4>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    else if (Rn <= 4)        launch_panel<4, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (Rn <= 8)   launch_panel<8, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (Rn <= 16)  launch_panel<16, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (Rn <= 32)  launch_panel<32, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
