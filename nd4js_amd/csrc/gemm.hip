@@ -165,13 +165,19 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
         b[j] = TB ? sb[(wn + j * 16 + fx) * LDR + kk * 4 + fk] : sb[(kk * 4 + fk) * LDK + wn + j * 16 + fx];
+      if (kk == BK / 4 - 1 && kt + 1 < nk) {
+        // stage tile kt+1 into the other LDS buffer BEFORE the last 16 MFMAs: the LDS writes drain behind
+        // them, so at the barrier nobody waits for vmcnt / the write pass (the other buffer is idle: its
+        // last reader passed the previous barrier)
+        sstore(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
 
