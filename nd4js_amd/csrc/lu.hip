@@ -55,7 +55,7 @@ __device__ __forceinline__ int block_argmax(PivCand c, PivCand* s_red, int* s_pi
 
 // ---- general panel kernel: panel lives in global memory (any m) ------------------------------
 __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+                                int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
   __shared__ PivCand s_red[16];
   __shared__ int s_piv;
   __shared__ double s_u[NB];
@@ -72,7 +72,8 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
       PivCand o{pivot_mag(A[(long)r * N + jc], r, jc), r};
       cand = better(cand, o);
     }
-    const int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    if (nopivot) piv = jc;
     if (t == 0) {
       ip[jc] = piv;
       if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
@@ -102,7 +103,7 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
 // unrolled so that every register index is static. 2 barriers per column.
 template <int R>
 __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
   __shared__ PivCand s_red[8];
   __shared__ double s_u[NB], s_j[NB];
   double* A = LU + blockIdx.x * strideM;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
       PivCand best = s_red[0];
 #pragma unroll
       for (int w = 1; w < 8; w++) best = better(best, s_red[w]);
-      const int piv = best.idx;
+      const int piv = nopivot ? jc : best.idx;
       if (t == 0) {
         ip[jc] = piv;
         if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
 // lane group g (16 lanes) owns rows j0 + g + 64*i; lane c of the group owns column j0 + c.
 template <int R>
 __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv) {
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
   __shared__ PivCand s_red[16];
   __shared__ int s_piv;
   __shared__ double s_u[NB], s_j[NB];
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, in
         cand = better(cand, o);
       }
     }
-    const int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    int piv = block_argmax(cand, s_red, &s_piv, t, T);
+    if (nopivot) piv = jc;
     if (t == 0) {
       ip[jc] = piv;
       if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
@@ -330,17 +332,17 @@ __global__ void iota_kernel(int32_t* __restrict__ P, int N, long total) {
 }
 
 template <int R>
-void launch_panel_row(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch) {
-  hipLaunchKernelGGL((lu_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+void launch_panel_row(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
+  hipLaunchKernelGGL((lu_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
 }
 template <int R>
-void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch) {
-  hipLaunchKernelGGL((lu_panel_reg<R>), dim3(batch), dim3(1024), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
+  hipLaunchKernelGGL((lu_panel_reg<R>), dim3(batch), dim3(1024), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
 }
 
 }  // namespace
 
-int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, double* LU, int32_t* P) {
+static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, double* LU, int32_t* P, int nopivot) {
   ND4_CHECK_ARG(N64 < (1ll << 30) && batch < 65536, "nd4_getrf: extent out of range");
   const int N = (int)N64;
   const long strideM = (long)N * N;
@@ -356,20 +358,20 @@ int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, dou
     const int nb = N - j0 < NB ? N - j0 : NB;
     const int m = N - j0;
     if (m >= 64 && m <= 2048) {
-      if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
-      else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
-      else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
     } else if (m > 2048 && m <= 64 * RMAX) {
       const int R = (m + 63) / 64;
-      if (R <= 8)       launch_panel_reg<8>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
-      else if (R <= 16) launch_panel_reg<16>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
-      else if (R <= 32) launch_panel_reg<32>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
-      else              launch_panel_reg<RMAX>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch);
+      if (R <= 8)       launch_panel_reg<8>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      else if (R <= 16) launch_panel_reg<16>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      else if (R <= 32) launch_panel_reg<32>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      else              launch_panel_reg<RMAX>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
     } else {
       int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
-      hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv);
+      hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
     }
-    if (N > nb)
+    if (N > nb && !nopivot)
       hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
                          LU, N, strideM, j0, nb, ipiv);
     const int rest = N - j0 - nb;
@@ -386,4 +388,12 @@ int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, dou
   }
   ND4_HIP(hipGetLastError());
   return 0;
+}
+
+int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
+  return getrf_impl(h, batch, N, A, LU, P, 0);
+}
+// Gaussian elimination WITHOUT pivoting (only the signs of the pivots are used: tall-QR sign convention, qr.hip)
+int nd4_getrf_nopivot(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
+  return getrf_impl(h, batch, N, A, LU, P, 1);
 }

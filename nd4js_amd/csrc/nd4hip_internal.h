@@ -49,6 +49,7 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
              double beta, double* C, int64_t ldc, int64_t sC, int64_t batch);
 
 int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+int nd4_getrf_nopivot(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);

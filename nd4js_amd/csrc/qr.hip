@@ -418,6 +418,16 @@ __global__ __launch_bounds__(256) void qr_tw(const double* __restrict__ Tall, lo
 
 // ------------------------------------------------------------------------------------ sign fix
 // One thread per matrix: decides the flips (reference convention, see file header).
+// Tall input (M > N) follows the reference's other branch (qr.js:97-139): every rotation is normalised to
+// c >= 0, which PRESERVES the sign of the pivot R_jj, so sign(R_jj) is whatever it was when row j finished its
+// own eliminations = sign(det A[0:j+1,0:j+1] / det A[0:j,0:j]). With A[0:k,0:k] = Q[0:k,0:k] R[0:k,0:k] the
+// flip of column j is the sign of the j-th pivot of Gaussian elimination WITHOUT pivoting on Q[0:N,0:N].
+__global__ void qr_flips_tall(const double* __restrict__ LUq, int N, int* __restrict__ flips, int batch) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)batch * N) return;
+  const long b = i / N, j = i % N;
+  flips[i] = LUq[b * N * N + j * N + j] < 0.0 ? 1 : 0;
+}
 __global__ void qr_flips(const double* __restrict__ Rm, long ldr, long strideR, const double* __restrict__ taus, long strideTau,
                          int M, int N, int L, int* __restrict__ flips, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,6 +562,16 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   }
 
   // ---- reference sign convention ----
+  if (tall) {
+    Nd4WsScope scope2(h);
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * N * N + sizeof(int32_t) * (size_t)batch * N, &q));
+    double* LUq = static_cast<double*>(q);
+    int32_t* Pq = reinterpret_cast<int32_t*>(LUq + (size_t)batch * N * N);
+    ND4_TRY(nd4_copy_matrix(h, N, N, Q, L, LUq, N, batch, sQ, (long)N * N));
+    ND4_TRY(nd4_getrf_nopivot(h, batch, N, LUq, LUq, Pq));
+    hipLaunchKernelGGL(qr_flips_tall, dim3((unsigned)(((long)batch * N + 255) / 256)), dim3(256), 0, h->stream, LUq, N, ws.flips, batch);
+  } else
   hipLaunchKernelGGL(qr_flips, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream,
                      R, (long)N, (long)L * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
   {
