@@ -22,6 +22,8 @@
 //   nd4_gemm   C -= V * W2 (gemm.hip, K = 16)
 // Q is formed by applying the block reflectors backwards to the identity with the same kernels.
 #include "nd4hip_internal.h"
+#include "dpp.h"
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -228,8 +230,9 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   }
   if (t < NB * (NB + 1)) (&s_T[0][0])[t] = 0.0;
 
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
+  // one column step per compile-time k (generic lambda, see lu.hip: convergent DPP ops block `#pragma unroll`)
+  auto column_step = [&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
     if (k < nb) {
       const int jc = j0 + k;
       double part = 0.0;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
         if (r > jc) part += a[i][k] * a[i][k];
       }
       if (t == k) s_alpha = a[0][k];
-      part = wave_sum(part);
+      part = nd4dpp::wave_sum(part);
       if (lane == 0) s_red[wave] = part;
       __syncthreads();
       double sigma = 0.0;
@@ -265,12 +268,12 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
       // halving butterfly over the 16 lanes of a group, then across the 4 groups of the wave
       double e8[8], e4[4], e2[2], e1;
 #pragma unroll
-      for (int j = 0; j < 8; j++) { const double snd = b0 ? d[j] : d[j + 8], kp = b0 ? d[j + 8] : d[j]; e8[j] = kp + __shfl_xor(snd, 1); }
+      for (int j = 0; j < 8; j++) { const double snd = b0 ? d[j] : d[j + 8], kp = b0 ? d[j + 8] : d[j]; e8[j] = kp + nd4dpp::xor1(snd); }
 #pragma unroll
-      for (int j = 0; j < 4; j++) { const double snd = b1 ? e8[j] : e8[j + 4], kp = b1 ? e8[j + 4] : e8[j]; e4[j] = kp + __shfl_xor(snd, 2); }
+      for (int j = 0; j < 4; j++) { const double snd = b1 ? e8[j] : e8[j + 4], kp = b1 ? e8[j + 4] : e8[j]; e4[j] = kp + nd4dpp::xor2(snd); }
 #pragma unroll
-      for (int j = 0; j < 2; j++) { const double snd = b2 ? e4[j] : e4[j + 2], kp = b2 ? e4[j + 2] : e4[j]; e2[j] = kp + __shfl_xor(snd, 4); }
-      { const double snd = b3 ? e2[0] : e2[1], kp = b3 ? e2[1] : e2[0]; e1 = kp + __shfl_xor(snd, 8); }
+      for (int j = 0; j < 2; j++) { const double snd = b2 ? e4[j] : e4[j + 2], kp = b2 ? e4[j + 2] : e4[j]; e2[j] = kp + nd4dpp::xor4(snd); }
+      { const double snd = b3 ? e2[0] : e2[1], kp = b3 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor8(snd); }
       e1 += __shfl_xor(e1, 16);
       e1 += __shfl_xor(e1, 32);
       if (lane < NB) s_w[wave][mycol] = e1;
@@ -299,7 +302,11 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-  }
+  };
+#define ND4_STEP(K) column_step(std::integral_constant<int, K>{});
+  ND4_STEP(0) ND4_STEP(1) ND4_STEP(2) ND4_STEP(3) ND4_STEP(4) ND4_STEP(5) ND4_STEP(6) ND4_STEP(7)
+  ND4_STEP(8) ND4_STEP(9) ND4_STEP(10) ND4_STEP(11) ND4_STEP(12) ND4_STEP(13) ND4_STEP(14) ND4_STEP(15)
+#undef ND4_STEP
   __syncthreads();
   if (t < nb) {                                          // larft: row t of T depends only on row t
     double row[NB];
