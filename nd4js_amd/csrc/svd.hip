@@ -265,6 +265,10 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
       ND4_HIP(hipStreamSynchronize(h->stream));
       sweeps++;
+      if (getenv("ND4HIP_SVD_DEBUG")) {
+        double r; unsigned long long bb = *h_off; memcpy(&r, &bb, 8);
+        fprintf(stderr, "[nd4hip svd] sweep %d: active matrices %u, max |cos| rotated %.3e\n", sweeps, h_active[0], sqrt(r));
+      }
       if (h_active[0] == 0) { last_off = *h_off; break; }
       last_off = *h_off;
       if (sweeps >= MAX_SWEEPS) break;
