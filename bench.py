@@ -106,7 +106,7 @@ def main():
                        "parallelism": "batch-sharded x%d, no collective" % world, "inputs": "uniform(-1,1) seeds 5/6, HBM-resident"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP64_TFLOPS, 4), "traffic": None,
-                         "kernel": "dgemm_kernel<NN,vec>", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "dgemm_kernel<NN,vec,full>", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 24.0 * n * n},
         }
         # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of this same command

@@ -45,7 +45,7 @@ struct GemmArgs {
 
 // ---- global -> register staging -------------------------------------------------------------
 // ROW operand: stored [x][k] (k contiguous). thread t covers x = q*32 + t/8, k = 2*(t%8)+{0,1}
-template <bool VEC>
+template <bool VEC, bool FULL>
 __device__ __forceinline__ void load_row(d2 (&r)[4], const double* __restrict__ P, long ld,
                                          int x0, int X, int k0, int K, int t) {
   const int kc = k0 + ((t & 7) << 1);
@@ -53,7 +53,9 @@ __device__ __forceinline__ void load_row(d2 (&r)[4], const double* __restrict__ 
   for (int q = 0; q < 4; q++) {
     const int x = x0 + q * 32 + (t >> 3);
     const double* p = P + (long)x * ld + kc;
-    if (VEC) {
+    if (FULL) {
+      r[q] = *reinterpret_cast<const d2*>(p);
+    } else if (VEC) {
       d2 v = {0.0, 0.0};
       if (x < X && kc < K) v = *reinterpret_cast<const d2*>(p);
       r[q] = v;
@@ -74,7 +76,7 @@ __device__ __forceinline__ void store_row(double* S, const d2 (&r)[4], int t) {
   }
 }
 // KMAJ operand: stored [k][x] (x contiguous). thread t covers k = t/16, x = q*32 + 2*(t%16)+{0,1}
-template <bool VEC>
+template <bool VEC, bool FULL>
 __device__ __forceinline__ void load_kmaj(d2 (&r)[4], const double* __restrict__ P, long ld,
                                           int x0, int X, int k0, int K, int t) {
   const int k = k0 + (t >> 4);
@@ -82,7 +84,9 @@ __device__ __forceinline__ void load_kmaj(d2 (&r)[4], const double* __restrict__
   for (int q = 0; q < 4; q++) {
     const int x = x0 + q * 32 + ((t & 15) << 1);
     const double* p = P + (long)k * ld + x;
-    if (VEC) {
+    if (FULL) {
+      r[q] = *reinterpret_cast<const d2*>(p);
+    } else if (VEC) {
       d2 v = {0.0, 0.0};
       if (k < K && x < X) v = *reinterpret_cast<const d2*>(p);
       r[q] = v;
@@ -101,7 +105,8 @@ __device__ __forceinline__ void store_kmaj(double* S, const d2 (&r)[4], int t) {
 }
 
 // TA: A is stored K x M (operand = transpose of the stored matrix); TB: B is stored N x K.
-template <bool TA, bool TB, bool VEC>
+// FULL: M, N multiples of 128 and K a multiple of 16 (and VEC): no bounds predicate anywhere.
+template <bool TA, bool TB, bool VEC, bool FULL>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double lds[4 * TILE];   // [buf][A|B][TILE]
 
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 
   d2 ra[4], rb[4];
   auto gload = [&](int k0) {
-    if (TA) load_kmaj<VEC>(ra, A, g.lda, m0, g.M, k0, g.K, t); else load_row<VEC>(ra, A, g.lda, m0, g.M, k0, g.K, t);
-    if (TB) load_row<VEC>(rb, B, g.ldb, n0, g.N, k0, g.K, t);  else load_kmaj<VEC>(rb, B, g.ldb, n0, g.N, k0, g.K, t);
+    if (TA) load_kmaj<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, g.K, t); else load_row<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, g.K, t);
+    if (TB) load_row<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, g.K, t);  else load_kmaj<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, g.K, t);
   };
   auto sstore = [&](int buf) {
     double* sa = lds + buf * 2 * TILE; double* sb = sa + TILE;
@@ -172,11 +177,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
         sstore(cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = m0 + wm + i * 16 + fk + 4 * r;
-        if (row < g.M && col < g.N) {
+        if (FULL || (row < g.M && col < g.N)) {
           double* c = C + (long)row * g.ldc + col;
           double v = alpha * acc[i][j][r];
           if (beta != 0.0) v += beta * *c;
@@ -204,8 +211,10 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 template <bool TA, bool TB>
 int launch(nd4hip_handle* h, const GemmArgs& g, bool vec, int64_t batch) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1), block(256, 1, 1);
-  if (vec) hipLaunchKernelGGL((dgemm_kernel<TA, TB, true>), grid, block, 0, h->stream, g);
-  else     hipLaunchKernelGGL((dgemm_kernel<TA, TB, false>), grid, block, 0, h->stream, g);
+  const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && g.K > 0;
+  if (full)     hipLaunchKernelGGL((dgemm_kernel<TA, TB, true, true>), grid, block, 0, h->stream, g);
+  else if (vec) hipLaunchKernelGGL((dgemm_kernel<TA, TB, true, false>), grid, block, 0, h->stream, g);
+  else          hipLaunchKernelGGL((dgemm_kernel<TA, TB, false, false>), grid, block, 0, h->stream, g);
   ND4_HIP(hipGetLastError());
   return 0;
 }
