@@ -55,6 +55,7 @@ __device__ __forceinline__ long pair_row(int x, int I, int J) { return x < BB ? 
 
 __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
                                                   const JacState* __restrict__ st, double* __restrict__ Gpart, int nchunks, long sG_mat) {
+  __shared__ double s_g[PB][PB + 1];
   const int pairIdx = blockIdx.x, chunk = blockIdx.y, mat = blockIdx.z;
   if (st[mat].done) return;
   int I, J;
@@ -66,28 +67,46 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   const double* rp[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) rp[t] = W + pair_row(t * 16 + fx, I, J) * N;
-  d4 acc[4];
+  // wave w owns columns [col0 + 64 w, +64) of the chunk and accumulates ALL 16 tiles over them: every
+  // fragment is loaded by exactly one wave (the earlier tile-row split loaded each fragment four times)
+  d4 acc[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int col0 = chunk * CH;
-#pragma unroll 8
-  for (int k8 = 0; k8 < CH / 8; k8++) {
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  const int col0 = chunk * CH + wave * (CH / 4);
+#pragma unroll 4
+  for (int k8 = 0; k8 < CH / 32; k8++) {
     const int c = col0 + k8 * 8 + 2 * fk;
     d2 f[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) f[t] = (c < N) ? *reinterpret_cast<const d2*>(rp[t] + c) : d2{0.0, 0.0};
-    const d2 fa = wave == 0 ? f[0] : (wave == 1 ? f[1] : (wave == 2 ? f[2] : f[3]));
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.x, f[j].x, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.y, f[j].y, acc[j], 0, 0, 0);
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].x, f[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].y, f[j].y, acc[i][j], 0, 0, 0);
+      }
+  }
+  // fixed-order reduction over the four waves through LDS (deterministic), then one coalesced store
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double* d = &s_g[i * 16 + fk + 4 * r][j * 16 + fx];
+            *d = (w == 0) ? acc[i][j][r] : *d + acc[i][j][r];
+          }
     }
+    __syncthreads();
   }
   double* G = Gpart + mat * sG_mat + ((long)pairIdx * nchunks + chunk) * (PB * PB);
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) G[(wave * 16 + fk + 4 * r) * PB + j * 16 + fx] = acc[j][r];
+  for (int e = threadIdx.x; e < PB * PB; e += 256) G[e] = s_g[e / PB][e % PB];
 }
 
 __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
