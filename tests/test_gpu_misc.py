@@ -1,0 +1,82 @@
+"""Cross-cutting GPU checks of the C ABI: run-to-run determinism (fixed reduction orders, no float atomics),
+argument validation, several handles / streams, and the LU behaviour on singular input."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from nd4js_amd import rng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    from nd4js_amd import la as _la
+    return _la
+
+
+def test_bitwise_reproducible(la):
+    a = rng.matrix(2001, 300, 300)
+    b = rng.matrix(2002, 300, 300)
+    x = rng.matrix(2003, 3, 128, 128)
+    for fn, args in ((la.matmul2, (a, b)), (la.lu_decomp, (a,)), (la.qr_decomp, (a,)), (la.svd_decomp, (a,)), (la.svd_decomp, (x,))):
+        r1 = fn(*args)
+        r2 = fn(*args)
+        r1 = r1 if isinstance(r1, tuple) else (r1,)
+        r2 = r2 if isinstance(r2, tuple) else (r2,)
+        for u, v in zip(r1, r2):
+            assert np.array_equal(u, v), fn.__name__
+
+
+def test_argument_validation_messages():
+    from nd4js_amd import _lib
+    lib = _lib.load()
+    h = _lib.handle(0)
+    rc = lib.nd4hip_dgemm_batched(h.ptr, 1, -1, 2, 2, None, 0, None, 0, None)
+    assert rc == -1 and b"negative extent" in lib.nd4hip_last_error()
+    rc = lib.nd4hip_dgemm_batched_dev(h.ptr, 2, 4, 4, 4, ctypes.c_void_p(8), 3, ctypes.c_void_p(8), 0, ctypes.c_void_p(8))
+    assert rc == -1 and b"strideA" in lib.nd4hip_last_error()
+    rc = lib.nd4hip_dgetrf_batched_dev(h.ptr, 1, 4, None, None, None)
+    assert rc == -1 and b"NULL" in lib.nd4hip_last_error()
+    rc = lib.nd4hip_dgemm_batched(None, 1, 1, 1, 1, None, 0, None, 0, None)
+    assert rc == -1 and b"NULL handle" in lib.nd4hip_last_error()
+    # zero-sized problems are no-ops
+    assert lib.nd4hip_dgemm_batched(h.ptr, 0, 4, 4, 4, None, 0, None, 0, None) == 0
+    assert lib.nd4hip_dgesvdj_batched(h.ptr, 0, 4, 4, None, None, None, None, None, None) == 0
+
+
+def test_two_handles_and_private_stream():
+    from nd4js_amd import _lib
+    h1, h2 = _lib.Handle(0), _lib.Handle(0)
+    a, b = rng.matrix(2010, 64, 64), rng.matrix(2011, 64, 64)
+    c1, c2 = np.empty((64, 64)), np.empty((64, 64))
+    p = lambda x: ctypes.c_void_p(x.ctypes.data)
+    _lib.check(h1.lib.nd4hip_dgemm_batched(h1.ptr, 1, 64, 64, 64, p(a), 0, p(b), 0, p(c1)))
+    _lib.check(h2.lib.nd4hip_dgemm_batched(h2.ptr, 1, 64, 64, 64, p(a), 0, p(b), 0, p(c2)))
+    assert np.array_equal(c1, c2)
+    h1.close(); h2.close()
+
+
+def test_singular_lu_matches_reference_pattern(la):
+    a = rng.matrix(2020, 24, 24)
+    a[:, 5] = 0.0                               # exact zero column -> a zero pivot, division by zero like lu.js:68
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a)
+    assert np.array_equal(np.isfinite(lu), np.isfinite(rlu))
+    fin = np.isfinite(rlu)
+    assert np.allclose(lu[fin], rlu[fin], rtol=1e-11, atol=1e-12)
+
+
+def test_large_batch_of_small_matrices(la):
+    a = rng.matrix(2030, 700, 9, 9)
+    lu, p = la.lu_decomp(a)
+    rlu, rp = oracle.lu_decomp(a)
+    assert np.array_equal(p, rp) and np.abs(lu - rlu).max() <= 1e-11
+    q, r = la.qr_decomp(a)
+    rq, rr = oracle.qr_decomp(a)
+    assert np.abs(q - rq).max() <= 1e-11 and np.abs(r - rr).max() <= 1e-11
+    u, sv, v = la.svd_decomp(a[:64])
+    _, rsv, _, _ = oracle.svd_jac_2sided(a[:64])
+    assert np.abs(sv - rsv).max() <= 1e-12 * rsv.max()
