@@ -115,7 +115,17 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
   for (int i = 0; i < R; i++) {
     const int r = j0 + t + 512 * i;
 #pragma unroll
-    for (int c = 0; c < NB; c++) a[i][c] = (r < N && c < nb) ? A[(long)r * N + j0 + c] : 0.0;
+    for (int c = 0; c < NB; c++) a[i][c] = 0.0;
+    if (r < N) {
+      const double* src = A + (long)r * N + j0;
+      if (nb == NB && (N & 1) == 0) {                    // 16-byte loads: each lane reads its own 128-B row segment
+#pragma unroll
+        for (int c = 0; c < NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < nb) a[i][c] = src[c];
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < NB; k++) {
@@ -195,8 +205,14 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
   for (int i = 0; i < R; i++) {
     const int r = j0 + t + 512 * i;
     if (r < N) {
+      double* dst = A + (long)r * N + j0;
+      if (nb == NB && (N & 1) == 0) {
 #pragma unroll
-      for (int c = 0; c < NB; c++) if (c < nb) A[(long)r * N + j0 + c] = a[i][c];
+        for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(dst + c) = double2{a[i][c], a[i][c + 1]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < nb) dst[c] = a[i][c];
+      }
     }
   }
 }

@@ -226,7 +226,17 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   for (int i = 0; i < R; i++) {
     const int r = j0 + t + 512 * i;
 #pragma unroll
-    for (int c = 0; c < NB; c++) a[i][c] = (r < M && c < nb) ? A[(long)r * ld + j0 + c] : 0.0;
+    for (int c = 0; c < NB; c++) a[i][c] = 0.0;
+    if (r < M) {
+      const double* src = A + (long)r * ld + j0;
+      if (nb == NB && (ld & 1) == 0) {                   // 16-byte loads of the lane's own 128-B row segment
+#pragma unroll
+        for (int c = 0; c < NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < nb) a[i][c] = src[c];
+      }
+    }
   }
   if (t < NB * (NB + 1)) (&s_T[0][0])[t] = 0.0;
 
@@ -330,14 +340,23 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   for (int i = 0; i < R; i++) {
     const int lr = t + 512 * i, r = j0 + lr;
     if (r < M) {
+      double* w = A + (long)r * ld + j0;
+      double* v = V + (long)r * ldv + j0;
+      double wv[NB], vv[NB];
 #pragma unroll
       for (int c = 0; c < NB; c++) {
-        if (c < nb) {
-          double* w = A + (long)r * ld + j0 + c;
-          double* v = V + (long)r * ldv + j0 + c;
-          if (lr <= c) { *w = a[i][c]; *v = (lr == c) ? 1.0 : 0.0; }
-          else { *w = 0.0; *v = a[i][c]; }
+        wv[c] = (lr <= c) ? a[i][c] : 0.0;                       // R part (upper triangle incl. diagonal)
+        vv[c] = (lr < c) ? 0.0 : ((lr == c) ? 1.0 : a[i][c]);    // explicit reflector: zeros above, unit diagonal
+      }
+      if (nb == NB && (ld & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; c += 2) {
+          *reinterpret_cast<double2*>(w + c) = double2{wv[c], wv[c + 1]};
+          *reinterpret_cast<double2*>(v + c) = double2{vv[c], vv[c + 1]};
         }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NB; c++) if (c < nb) { w[c] = wv[c]; v[c] = vv[c]; }
       }
     }
   }
