@@ -454,19 +454,23 @@ __global__ void qr_flips_tall(const double* __restrict__ LUq, int N, int* __rest
   const long b = i / N, j = i % N;
   flips[i] = LUq[b * N * N + j * N + j] < 0.0 ? 1 : 0;
 }
-__global__ void qr_flips(const double* __restrict__ Rm, long ldr, long strideR, const double* __restrict__ taus, long strideTau,
-                         int M, int N, int L, int* __restrict__ flips, int batch) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
+__global__ __launch_bounds__(256) void qr_flips(const double* __restrict__ Rm, long ldr, long strideR, const double* __restrict__ taus, long strideTau,
+                                                 int M, int N, int L, int* __restrict__ flips, int batch) {
+  // one workgroup per matrix: flags in parallel, parity by a block-wide XOR
+  const int b = blockIdx.x;
   const double* R = Rm + b * strideR; const double* tau = taus + b * strideTau; int* f = flips + (long)b * L;
+  __shared__ int s_par[4];
   int parity = 0;
-  for (int j = 0; j < L; j++) {
+  for (int j = threadIdx.x; j < L; j += 256) {
     int fl = 0;
     if (tau[j] != 0.0) { parity ^= 1; if (R[(long)j * ldr + j] < 0.0) { fl = 1; parity ^= 1; } }
     f[j] = fl;
   }
+  parity = __popcll(__ballot(parity)) & 1;
+  if ((threadIdx.x & 63) == 0) s_par[threadIdx.x >> 6] = parity;
+  __syncthreads();
   // plane rotations never change the determinant: det(Q) = +1 whenever Q is square (M <= N)
-  if (M <= N && parity) f[L - 1] ^= 1;
+  if (threadIdx.x == 0 && M <= N && ((s_par[0] ^ s_par[1] ^ s_par[2] ^ s_par[3]) & 1)) f[L - 1] ^= 1;
 }
 // scale rows of R (rows x cols, ld) by -1 where flips[row]
 __global__ void qr_flip_rows(double* __restrict__ X, long ld, long strideX, int rows, int cols, const int* __restrict__ flips, int L) {
@@ -598,7 +602,7 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
     ND4_TRY(nd4_getrf_nopivot(h, batch, N, LUq, LUq, Pq));
     hipLaunchKernelGGL(qr_flips_tall, dim3((unsigned)(((long)batch * N + 255) / 256)), dim3(256), 0, h->stream, LUq, N, ws.flips, batch);
   } else
-  hipLaunchKernelGGL(qr_flips, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream,
+  hipLaunchKernelGGL(qr_flips, dim3((unsigned)batch), dim3(256), 0, h->stream,
                      R, (long)N, (long)L * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
   {
     const unsigned gy = (unsigned)(L < 512 ? L : 512);
