@@ -48,10 +48,18 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
         ms = _time(lambda: dev.svd_decomp(A9, info=info), h, 1)
         f = 21.0 * N ** 3
         sweeps = info.get("sweeps", 0)
+        blocked = (N % 64 == 0 and N >= 128)
+        nblk = N // 32
+        if blocked:      # block Jacobi (svd_block.hip): per sweep 12 N^3 flop on MFMA, 5 passes over W/Ut per step
+            ex_flops = 12.0 * N ** 3 * sweeps
+            ex_bytes = 40.0 * N * N * (nblk - 1) * sweeps
+        else:            # row-pair Jacobi (svd.hip): SURVEY.md §8d
+            ex_flops = 7.0 * N * N * (N - 1) * sweeps
+            ex_bytes = 32.0 * N * N * (N - 1) * sweeps
         out["svd%d" % N] = {"ms": round(ms, 2), "gflops_nominal": round(f / ms / 1e6, 1), "sweeps": sweeps,
-                            "jacobi_executed_gflops": round(7.0 * N * N * (N - 1) * sweeps / ms / 1e6, 1),
-                            "jacobi_sweep_traffic_GBps": round(32.0 * N * N * (N - 1) * sweeps / ms / 1e6, 1),
-                            "frac_hbm_peak": round(32.0 * N * N * (N - 1) * sweeps / ms / 1e6 / PEAK_HBM_GBS, 4),
+                            "algorithm": "block one-sided Jacobi (32-row blocks, Gram/eigen/apply on MFMA)" if blocked else "row-pair one-sided Jacobi",
+                            "executed_gflops": round(ex_flops / ms / 1e6, 1), "executed_frac_mfma_peak": round(ex_flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                            "executed_traffic_GBps": round(ex_bytes / ms / 1e6, 1), "executed_frac_hbm_peak": round(ex_bytes / ms / 1e6 / PEAK_HBM_GBS, 4),
                             "offnorm": info.get("offnorm")}
     # ---- batched SVD, batch axis sharded over ranks ----
     B = int(os.environ.get("ND4_BENCH_SVD_BATCH", svd_batch or 1024))

@@ -53,6 +53,44 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 __device__ __forceinline__ long pair_row(int x, int I, int J) { return x < BB ? (long)I * BB + x : (long)J * BB + (x - BB); }
 
+// acc (16 tiles of the 64x64 Gram of the block pair) over the columns [col0, col0 + ncols) of W, for one wave.
+// The A and B fragments of a Gram product are the same register image; one 16-byte load feeds two MFMA k-steps.
+__device__ __forceinline__ void gram_accumulate(d4 (&acc)[4][4], const double* const (&rp)[4], int col0, int ncols, int N, int fk) {
+#pragma unroll 8
+  for (int k8 = 0; k8 < ncols / 8; k8++) {
+    const int c = col0 + k8 * 8 + 2 * fk;
+    d2 f[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) f[t] = (c < N) ? *reinterpret_cast<const d2*>(rp[t] + c) : d2{0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].x, f[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].y, f[j].y, acc[i][j], 0, 0, 0);
+      }
+  }
+}
+// fixed-order (deterministic) reduction of the four waves' tiles into an LDS image G[64][ldg]
+template <int LDG>
+__device__ __forceinline__ void gram_reduce_lds(double (*G)[LDG], const d4 (&acc)[4][4], int wave, int fk, int fx) {
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double* d = &G[i * 16 + fk + 4 * r][j * 16 + fx];
+            *d = (w == 0) ? acc[i][j][r] : *d + acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
                                                   const JacState* __restrict__ st, double* __restrict__ Gpart, int nchunks, long sG_mat) {
   __shared__ double s_g[PB][PB + 1];
@@ -68,47 +106,22 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
 #pragma unroll
   for (int t = 0; t < 4; t++) rp[t] = W + pair_row(t * 16 + fx, I, J) * N;
   // wave w owns columns [col0 + 64 w, +64) of the chunk and accumulates ALL 16 tiles over them: every
-  // fragment is loaded by exactly one wave (the earlier tile-row split loaded each fragment four times)
+  // fragment is loaded by exactly one wave
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  const int col0 = chunk * CH + wave * (CH / 4);
-#pragma unroll 4
-  for (int k8 = 0; k8 < CH / 32; k8++) {
-    const int c = col0 + k8 * 8 + 2 * fk;
-    d2 f[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) f[t] = (c < N) ? *reinterpret_cast<const d2*>(rp[t] + c) : d2{0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].x, f[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].y, f[j].y, acc[i][j], 0, 0, 0);
-      }
-  }
-  // fixed-order reduction over the four waves through LDS (deterministic), then one coalesced store
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    if (wave == w) {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            double* d = &s_g[i * 16 + fk + 4 * r][j * 16 + fx];
-            *d = (w == 0) ? acc[i][j][r] : *d + acc[i][j][r];
-          }
-    }
-    __syncthreads();
-  }
+  gram_accumulate(acc, rp, chunk * CH + wave * (CH / 4), CH / 4, N, fk);
+  gram_reduce_lds<PB + 1>(s_g, acc, wave, fk, fx);
   double* G = Gpart + mat * sG_mat + ((long)pairIdx * nchunks + chunk) * (PB * PB);
   for (int e = threadIdx.x; e < PB * PB; e += 256) G[e] = s_g[e / PB][e % PB];
 }
 
+// FUSED: the workgroup computes the Gram matrix of its block pair itself (small N: the MFMA phase of one
+// workgroup overlaps the LDS-bound rotation rounds of the other workgroup on the CU, and the partial-Gram
+// round trip through HBM disappears); Gpart then carries W and nchunks carries N.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                                    JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
                                                    double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
@@ -122,12 +135,29 @@ __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpa
   nd4_rr_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
-  for (int e = t; e < PB * PB; e += 256) {
-    double s = 0.0;
-    for (int ch = 0; ch < nchunks; ch++) s += Gp[(long)ch * (PB * PB) + e];
-    G[e / PB][e % PB] = s;
-    Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+  if (FUSED) {
+    const int N = nchunks, fx = lane & 15, fk = lane >> 4;
+    const double* W = Gpart + mat * sG_mat;
+    const double* rp[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) rp[q] = W + pair_row(q * 16 + fx, I, J) * N;
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    const int per = ((N + 31) / 32) * 8;                      // columns per wave, multiple of 8
+    gram_accumulate(acc, rp, wave * per, per, N, fk);
+    gram_reduce_lds<PB + 1>(G, acc, wave, fk, fx);
+    for (int e = t; e < PB * PB; e += 256) Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+  } else {
+    const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
+    for (int e = t; e < PB * PB; e += 256) {
+      double s = 0.0;
+      for (int ch = 0; ch < nchunks; ch++) s += Gp[(long)ch * (PB * PB) + e];
+      G[e / PB][e % PB] = s;
+      Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+    }
   }
   __syncthreads();
   const double fl = floor2[mat];
@@ -280,11 +310,22 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   static const int max_inner = getenv("ND4HIP_JAC_INNER") ? atoi(getenv("ND4HIP_JAC_INNER")) : MAX_INNER_DEFAULT;
   static const int cross = getenv("ND4HIP_JAC_CROSS") ? atoi(getenv("ND4HIP_JAC_CROSS")) : 1;
   for (int step = 0; step < nblk2 - 1; step++) {
-    hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
-                       W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
-    hipLaunchKernelGGL(jacb_eigen, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
-                       Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
-                       (cross && step > 0) ? 1 : 0);
+    static const int fuse_env = getenv("ND4HIP_JAC_FUSE") ? atoi(getenv("ND4HIP_JAC_FUSE")) : -1;
+    // fused Gram+eigen pays when the (pair, matrix) workgroups alone fill the chip about once or twice; with many
+    // more of them the separate, fully parallel Gram launch hides its load latency better (measured at N = 512:
+    // batch 64: 83 -> 52 ms fused; batch 128: 94 -> 102; batch 1024: 738 -> 790)
+    const bool fused = fuse_env >= 0 ? fuse_env != 0 : (N <= 1024 && batch * npairs >= 128 && batch * npairs <= 768);
+    if (fused) {
+      hipLaunchKernelGGL(jacb_eigen<true>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
+                         W, N, sM, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
+                         (cross && step > 0) ? 1 : 0);
+    } else {
+      hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
+                         W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+      hipLaunchKernelGGL(jacb_eigen<false>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
+                         Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
+                         (cross && step > 0) ? 1 : 0);
+    }
     hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
                        W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks);
   }
