@@ -43,6 +43,13 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
         f = 8.0 / 3.0 * N ** 3
         out["qr%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
                            "algorithmic_flops": f}
+        # N1: lu_solve with N right-hand sides on the device-resident factors: 2 N^2 J flop
+        LUd, Pd = dev.lu_decomp(A)
+        Y = dev.fill_uniform(11, (N, N))
+        ms = _time(lambda: dev.lu_solve(LUd, Pd, Y), h, 5)
+        f = 2.0 * N * N * N
+        out["lu_solve%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                                 "rhs_columns": N, "algorithmic_flops": f}
         A9 = dev.fill_uniform(9, (N, N))
         info = {}
         ms = _time(lambda: dev.svd_decomp(A9, info=info), h, 1)

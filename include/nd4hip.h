@@ -82,6 +82,23 @@ int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int64_t M, int
 int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4hip_dgetrf_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 
+/* ---- lu_solve: replaces src/la/lu.js:84-177 -------------------------------------
+ * X [batch,N,J] = U^-1 L^-1 Y[P,:] for LU/P as returned by dgetrf. strides in ELEMENTS between consecutive
+ * batch members, 0 = the operand is broadcast over the batch (lu.js:148-163 broadcasting, flattened by
+ * the host wrapper). */
+int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
+                              const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X);
+int nd4hip_dgetrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
+                              const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X);
+
+/* ---- tril_solve / triu_solve: replace src/la/tri.js:155-290 (kernels :45-95) ----------------------
+ * X [batch,M,J] = T^-1 Y with T [batch,M,M] lower (upper = 0) or upper (upper != 0) triangular; only that
+ * triangle of T is read; unit_diag != 0 treats the diagonal as ones. strideT / strideY = 0 broadcast. */
+int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
+                             const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X);
+int nd4hip_dtrsm_batched    (nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
+                             const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X);
+
 /* ---- qr_decomp: replaces src/la/qr.js:80-145 / qr_decomp_full :27-77 ----------------------------
  * A [batch,M,N] -> Q [batch,M,L], R [batch,L,N], L = min(M,N); blocked Householder with the
  * reference's Givens sign convention restored (R_jj >= 0 wherever a column had something to

@@ -30,6 +30,8 @@ static int (*p_dgemm)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, const 
 static int (*p_dgetrf)(nd4hip_handle*, int64_t, int64_t, const double*, double*, int32_t*);
 static int (*p_dgeqrf)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*);
 static int (*p_dgesvdj)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*, int*, double*);
+static int (*p_dgetrs)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const int32_t*, int64_t, const double*, int64_t, double*);
+static int (*p_dtrsm)(nd4hip_handle*, int, int, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
 
 static char g_load_error[512] = "";
 
@@ -63,6 +65,8 @@ static int load_library(void) {
   SYM(p_dgetrf, "nd4hip_dgetrf_batched");
   SYM(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
   SYM(p_dgesvdj, "nd4hip_dgesvdj_batched");
+  SYM(p_dgetrs, "nd4hip_dgetrs_batched");
+  SYM(p_dtrsm, "nd4hip_dtrsm_batched");
 #undef SYM
   return 0;
 }
@@ -184,6 +188,42 @@ static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
   return r;
 }
 
+/* dgetrs_batched(batch, N, J, LU, strideLU, P, strideP, Y, strideY, X)   (lu_solve, lu.js:84-177) */
+static napi_value js_dgetrs(napi_env env, napi_callback_info info) {
+  size_t argc = 10; napi_value a[10];
+  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
+  NEED(argc == 10, "dgetrs_batched: 10 arguments expected");
+  int64_t batch, N, J, sLU, sP, sY; void *LU, *P, *Y, *X; size_t nLU, nP, nY, nX;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &J) ||
+      get_ta(env, a[3], napi_float64_array, &LU, &nLU) || get_i64(env, a[4], &sLU) ||
+      get_ta(env, a[5], napi_int32_array, &P, &nP) || get_i64(env, a[6], &sP) ||
+      get_ta(env, a[7], napi_float64_array, &Y, &nY) || get_i64(env, a[8], &sY) ||
+      get_ta(env, a[9], napi_float64_array, &X, &nX)) return NULL;
+  NEED(batch >= 0 && N >= 0 && J >= 0 && sLU >= 0 && sP >= 0 && sY >= 0, "dgetrs_batched: negative extent");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sLU + N * N) <= nLU && (size_t)((batch - 1) * sP + N) <= nP &&
+                      (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * N * J) <= nX), "dgetrs_batched: buffer too small");
+  if (ensure_handle(env)) return NULL;
+  if (p_dgetrs(g_handle, batch, N, J, (const double*)LU, sLU, (const int32_t*)P, sP, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  return NULL;
+}
+/* dtrsm_batched(upper, unit_diag, batch, M, J, T, strideT, Y, strideY, X)   (tril_solve / triu_solve, tri.js:155-290) */
+static napi_value js_dtrsm(napi_env env, napi_callback_info info) {
+  size_t argc = 10; napi_value a[10];
+  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
+  NEED(argc == 10, "dtrsm_batched: 10 arguments expected");
+  int64_t upper, unit, batch, M, J, sT, sY; void *T, *Y, *X; size_t nT, nY, nX;
+  if (get_i64(env, a[0], &upper) || get_i64(env, a[1], &unit) || get_i64(env, a[2], &batch) || get_i64(env, a[3], &M) || get_i64(env, a[4], &J) ||
+      get_ta(env, a[5], napi_float64_array, &T, &nT) || get_i64(env, a[6], &sT) ||
+      get_ta(env, a[7], napi_float64_array, &Y, &nY) || get_i64(env, a[8], &sY) ||
+      get_ta(env, a[9], napi_float64_array, &X, &nX)) return NULL;
+  NEED(batch >= 0 && M >= 0 && J >= 0 && sT >= 0 && sY >= 0, "dtrsm_batched: negative extent");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sT + M * M) <= nT && (size_t)((batch - 1) * sY + M * J) <= nY && (size_t)(batch * M * J) <= nX),
+       "dtrsm_batched: buffer too small");
+  if (ensure_handle(env)) return NULL;
+  if (p_dtrsm(g_handle, (int)upper, (int)unit, batch, M, J, (const double*)T, sT, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  return NULL;
+}
+
 static void cleanup(void* arg) {
   (void)arg;
   if (g_handle && p_destroy) { p_destroy(g_handle); g_handle = NULL; }
@@ -197,6 +237,8 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dgetrf_batched", NULL, js_dgetrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgesvdj_batched", NULL, js_dgesvdj, NULL, NULL, NULL, napi_default, NULL},
+    {"dgetrs_batched", NULL, js_dgetrs, NULL, NULL, NULL, napi_default, NULL},
+    {"dtrsm_batched", NULL, js_dtrsm, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   napi_add_env_cleanup_hook(env, cleanup, NULL);

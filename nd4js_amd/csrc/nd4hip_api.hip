@@ -95,6 +95,73 @@ extern "C" int nd4hip_dgetrf_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   return 0;
 }
 
+// ------------------------------------------------------------------------------------ solves
+namespace {
+// X[b] = Y[b*strideY] for every batch member (strideY = 0: the same Y for all)
+int copy_rhs(nd4hip_handle* h, int64_t batch, int64_t rows, int64_t J, const double* Y, int64_t strideY, double* X) {
+  return nd4_copy_matrix(h, rows, J, Y, J, X, J, batch, strideY, rows * J);
+}
+}  // namespace
+
+extern "C" int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
+                                         const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dgetrs_batched: negative extent");
+  ND4_CHECK_ARG((strideLU == 0 || strideLU >= N * N) && (strideP == 0 || strideP >= N) && (strideY == 0 || strideY >= N * J),
+                "nd4hip_dgetrs_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(LU && P && Y && X, "nd4hip_dgetrs_batched: NULL pointer");
+  return nd4_getrs(h, batch, N, J, LU, strideLU, P, strideP, Y, strideY, X);
+}
+extern "C" int nd4hip_dgetrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
+                                     const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dgetrs_batched: negative extent");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nLU = (size_t)(strideLU ? (batch - 1) * strideLU + N * N : N * N);
+  const size_t nP = (size_t)(strideP ? (batch - 1) * strideP + N : N);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
+  const size_t nX = (size_t)(batch * N * J);
+  DevBuf dLU, dP, dY, dX;
+  ND4_TRY(dLU.alloc(nLU * D)); ND4_TRY(dP.alloc(nP * 4)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  ND4_TRY(h2d(h, dLU.p, LU, nLU * D)); ND4_TRY(h2d(h, dP.p, P, nP * 4)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dgetrs_batched_dev(h, batch, N, J, (const double*)dLU.p, strideLU, (const int32_t*)dP.p, strideP,
+                                    (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
+                                        const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dtrsm_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && J >= 0, "nd4hip_dtrsm_batched: negative extent");
+  ND4_CHECK_ARG((strideT == 0 || strideT >= M * M) && (strideY == 0 || strideY >= M * J),
+                "nd4hip_dtrsm_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || M == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(T && Y && X, "nd4hip_dtrsm_batched: NULL pointer");
+  if (X != Y || strideY != M * J) ND4_TRY(copy_rhs(h, batch, M, J, Y, strideY, X));
+  return nd4_trsm(h, upper != 0, unit_diag != 0, batch, M, J, T, strideT, X);
+}
+extern "C" int nd4hip_dtrsm_batched(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
+                                    const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dtrsm_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && J >= 0, "nd4hip_dtrsm_batched: negative extent");
+  if (batch == 0 || M == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nT = (size_t)(strideT ? (batch - 1) * strideT + M * M : M * M);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + M * J : M * J);
+  const size_t nX = (size_t)(batch * M * J);
+  DevBuf dT, dY, dX;
+  ND4_TRY(dT.alloc(nT * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  ND4_TRY(h2d(h, dT.p, T, nT * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dtrsm_batched_dev(h, upper, unit_diag, batch, M, J, (const double*)dT.p, strideT, (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ QR
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");

@@ -50,6 +50,9 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
 
 int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4_getrf_nopivot(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
+int nd4_trsm(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t M, int64_t J, const double* T, int64_t sT, double* X);
+int nd4_getrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t sLU, const int32_t* P, int64_t sP,
+              const double* Y, int64_t sY, double* X);
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);

@@ -114,3 +114,34 @@ def svd_decomp(A, info=None):
     if info is not None:
         info["sweeps"], info["offnorm"] = sweeps.value, off.value
     return U, sv, V
+
+
+def lu_solve(LU, P, Y):
+    """device-resident lu_solve (lu.js:84-177): LU [..., N, N], P [..., N] int32, Y [..., N, J] with equal leading dims"""
+    _chk(LU, "LU"), _chk(Y, "Y")
+    N, J = Y.shape[-2:]
+    if LU.shape[-1] != N or LU.shape[-2] != N:
+        raise ValueError("LU and y don't match.")
+    lead = tuple(Y.shape[:-2])
+    if tuple(LU.shape[:-2]) != lead or tuple(P.shape[:-1]) != lead:
+        raise ValueError("LU and y are not broadcast-compatible.")   # general broadcasting: host wrapper (la.py)
+    X = torch.empty(lead + (N, J), dtype=torch.float64, device=Y.device)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dgetrs_batched_dev(h.ptr, b, N, J, _p(LU), N * N if b > 1 else 0, ctypes.c_void_p(P.data_ptr()), N if b > 1 else 0,
+                                               _p(Y), N * J if b > 1 else 0, _p(X)))
+    return X
+
+
+def tri_solve(T, Y, upper, unit_diag=False):
+    _chk(T, "T"), _chk(Y, "Y")
+    M, J = Y.shape[-2:]
+    lead = tuple(Y.shape[:-2])
+    if tuple(T.shape[:-2]) != lead or T.shape[-1] != M or T.shape[-2] != M:
+        raise ValueError("T and Y don't match.")
+    X = torch.empty_like(Y)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dtrsm_batched_dev(h.ptr, int(bool(upper)), int(bool(unit_diag)), b, M, J, _p(T), M * M if b > 1 else 0,
+                                              _p(Y), M * J if b > 1 else 0, _p(X)))
+    return X

@@ -102,6 +102,44 @@ function bcastGroups(lead, la, lb, IK, KJ) {
   return groups;
 }
 
+/* n-operand form of bcastGroups: [count, [offsets], [strides], outIndex] with stride_k in {0, units[k]} */
+function bcastGroupsN(lead, shapes, units) {
+  const nb = lead.length, total = lead.reduce((a, b) => a * b, 1);
+  const offs = shapes.map((sh, k) => {
+    const s = Array(nb - sh.length).fill(1).concat(Array.from(sh)), st = Array(nb).fill(0);
+    let u = units[k]; for (let d = nb - 1; d >= 0; d--) { st[d] = s[d] > 1 ? u : 0; u *= s[d]; }
+    const o = new Float64Array(total), idx = Array(nb).fill(0);
+    for (let b = 0; b < total; b++) {
+      let a = 0; for (let d = 0; d < nb; d++) a += idx[d] * st[d];
+      o[b] = a;
+      for (let d = nb - 1; d >= 0; d--) { if (++idx[d] < lead[d]) break; idx[d] = 0; }
+    }
+    return o;
+  });
+  const groups = [];
+  for (let b0 = 0; b0 < total;) {
+    let b1 = b0 + 1, strides = units.map(() => 0);
+    if (b1 < total) {
+      const cand = offs.map(o => o[b1] - o[b0]);
+      if (cand.every((c, k) => c === 0 || c === units[k])) {
+        strides = cand;
+        while (b1 < total && offs.every((o, k) => o[b1] - o[b1 - 1] === cand[k])) b1++;
+      }
+    }
+    groups.push([b1 - b0, offs.map(o => o[b0]), strides, b0]);
+    b0 = b1;
+  }
+  return groups;
+}
+function bcastLead(shapes, err) {            // common leading shape, NumPy rules
+  const nb = Math.max(...shapes.map(s => s.length)), lead = Array(nb).fill(1);
+  for (const sh of shapes)
+    for (let i = nb, j = sh.length; i-- > 0 && j-- > 0;)
+      if (lead[i] === 1) lead[i] = sh[j];
+      else if (lead[i] != sh[j] && sh[j] != 1) throw new Error(err);
+  return lead;
+}
+
 function makeLa(NDA, fallback) {
   const asarray = makeAsarray(NDA);
   const gpuOk = a => { const d = dtypeOf(a); return d === 'float64' || d === 'int32'; };
@@ -207,6 +245,47 @@ function makeLa(NDA, fallback) {
     return [new NDA(Us, U), new NDA(Int32Array.from(Us.subarray(0, nd_ - 1)), sv), new NDA(Vs, V)];
   };
   la.svd_dc = la.svd_decomp;
+
+  /* ---- SURVEY §8f N1: solve-side consumers (csrc/trsm.hip) ---- */
+  const triSolve = (upper, name, T, Y) => {
+    T = asarray(T); Y = asarray(Y);
+    const tn = upper ? 'U' : 'L';
+    if (T.ndim < 2) throw new Error(`${name}(${tn},Y): ${tn}.ndim must be at least 2.`);
+    if (Y.ndim < 2) throw new Error(`${name}(${tn},Y): Y.ndim must be at least 2.`);
+    const M = Y.shape[Y.ndim - 2], J = Y.shape[Y.ndim - 1];
+    if (T.shape[T.ndim - 2] !== M) throw new Error(`${name}(${tn},Y): ${tn} and Y don't match.`);
+    if (T.shape[T.ndim - 1] !== M) throw new Error(`${name}(${tn},Y): Last two dimensions of ${tn} must be quadratic.`);
+    if (!gpuOk(T) || !gpuOk(Y)) { if (fallback && fallback[name]) return fallback[name](T, Y); throw new Error(`nd4hip.${name}: dtype is not accelerated.`); }
+    const lead = bcastLead([Array.from(T.shape.subarray(0, T.ndim - 2)), Array.from(Y.shape.subarray(0, Y.ndim - 2))], `${name}(${tn},Y): ${tn} and Y not broadcast-compatible.`);
+    const Td = f64(T), Yd = f64(Y), X = new Float64Array(lead.reduce((a, b) => a * b, 1) * M * J);
+    for (const [cnt, [oT, oY], [sT, sY], b0] of bcastGroupsN(lead, [T.shape.subarray(0, T.ndim - 2), Y.shape.subarray(0, Y.ndim - 2)], [M * M, M * J]))
+      native().dtrsm_batched(upper ? 1 : 0, 0, cnt, M, J, Td.subarray(oT), sT, Yd.subarray(oY), sY, X.subarray(b0 * M * J));
+    return new NDA(Int32Array.from([...lead, M, J]), X);
+  };
+  la.tril_solve = (L, Y) => triSolve(false, 'tril_solve', L, Y);
+  la.triu_solve = (U, Y) => triSolve(true, 'triu_solve', U, Y);
+
+  la.lu_solve = function lu_solve(LU, P, y) {
+    if (undefined == y) { y = P; [LU, P] = LU; }
+    LU = asarray(LU); if (LU.ndim < 2) throw new Error('LU must be at least 2D.');
+    P = asarray(P); if (P.ndim < 1) throw new Error('P must be at least 1D.');
+    y = asarray(y); if (y.ndim < 2) throw new Error('y must be at least 2D.');
+    const N = LU.shape[LU.ndim - 2], I = y.shape[y.ndim - 2], J = y.shape[y.ndim - 1];
+    if (LU.shape[LU.ndim - 1] != N) throw new Error('Last two dimensions of LU must be quadratic.');
+    if (N != I) throw new Error("LU and y don't match.");
+    if (N != P.shape[P.ndim - 1]) throw new Error("LU and P don't match.");
+    if (!gpuOk(LU) || !gpuOk(y) || !(P.data instanceof Int32Array)) {
+      if (fallback && fallback.lu_solve) return fallback.lu_solve(LU, P, y);
+      throw new Error('nd4hip.lu_solve: dtype is not accelerated.');
+    }
+    const lLU = Array.from(LU.shape.subarray(0, LU.ndim - 2)), lP = Array.from(P.shape.subarray(0, P.ndim - 1)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
+    let lead = bcastLead([lLU, lY], 'LU and y are not broadcast-compatible.');
+    lead = bcastLead([lead, lP], 'P is not broadcast-compatible.');
+    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * N * J), LUd = f64(LU), yd = f64(y);
+    for (const [cnt, [oLU, oP, oY], [sLU, sP, sY], b0] of bcastGroupsN(lead, [lLU, lP, lY], [N * N, N, N * J]))
+      native().dgetrs_batched(cnt, N, J, LUd.subarray(oLU), sLU, P.data.subarray(oP), sP, yd.subarray(oY), sY, X.subarray(b0 * N * J));
+    return new NDA(Int32Array.from([...lead, N, J]), X);
+  };
   return la;
 }
 
@@ -216,7 +295,8 @@ const standalone = makeLa(NDArray, null);
 function install(nd) {
   if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp,
-                    lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc};
+                    lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
+                    lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

@@ -182,3 +182,103 @@ def svd_decomp(A, device=None, info=None):
 
 
 svd_dc = svd_decomp
+
+
+# ---------------------------------------------------------------------------------------------------
+# solve-side consumers of the path, device kernels in csrc/trsm.hip
+# ---------------------------------------------------------------------------------------------------
+def _bcast_groups_n(lead, shapes, units):
+    """n-operand form of _bcast_groups: yields (count, [offset_k], [stride_k], out_index) with every stride in
+    {0, units[k]} (what the odometers at lu.js:148-163 / tri.js:193-215 do one matrix at a time)."""
+    nb = len(lead)
+    total = int(np.prod(lead, dtype=np.int64)) if nb else 1
+    offs = []
+    for shp, unit in zip(shapes, units):
+        shp = (1,) * (nb - len(shp)) + tuple(shp)
+        offs.append(np.broadcast_to((np.arange(int(np.prod(shp, dtype=np.int64)), dtype=np.int64) * unit).reshape(shp), lead).reshape(-1))
+    groups, b0 = [], 0
+    while b0 < total:
+        b1, strides = b0 + 1, [0] * len(offs)
+        if b1 < total:
+            cand = [int(o[b1] - o[b0]) for o in offs]
+            if all(c in (0, u) for c, u in zip(cand, units)):
+                strides = cand
+                while b1 < total and all(int(o[b1] - o[b1 - 1]) == c for o, c in zip(offs, cand)):
+                    b1 += 1
+        groups.append((b1 - b0, [int(o[b0]) for o in offs], strides, b0))
+        b0 = b1
+    return groups
+
+
+def _off(a, elems, itemsize=8):
+    return ctypes.c_void_p(a.ctypes.data + itemsize * elems)
+
+
+def _tri_solve(upper, T, Y, name, device=None):
+    T = _asarray(T, name)
+    Y = _asarray(Y, name)
+    if T.ndim < 2:
+        raise ValueError("%s: %s.ndim must be at least 2." % (name, "U" if upper else "L"))
+    if Y.ndim < 2:
+        raise ValueError("%s: Y.ndim must be at least 2." % name)
+    M, J = Y.shape[-2:]
+    if T.shape[-2] != M:
+        raise ValueError("%s: %s and Y don't match." % (name, "U" if upper else "L"))
+    if T.shape[-1] != M:
+        raise ValueError("%s: Last two dimensions of %s must be quadratic." % (name, "U" if upper else "L"))
+    try:
+        lead = np.broadcast_shapes(T.shape[:-2], Y.shape[:-2])
+    except ValueError:
+        raise ValueError("%s: %s and Y not broadcast-compatible." % (name, "U" if upper else "L"))
+    X = np.empty(tuple(lead) + (M, J))
+    h = _lib.handle(device)
+    for cnt, (oT, oY), (sT, sY), b0 in _bcast_groups_n(tuple(lead), [T.shape[:-2], Y.shape[:-2]], [M * M, M * J]):
+        _lib.check(h.lib.nd4hip_dtrsm_batched(h.ptr, 1 if upper else 0, 0, cnt, M, J, _off(T, oT), sT, _off(Y, oY), sY, _off(X, b0 * M * J)))
+    return X
+
+
+def tril_solve(L, Y, device=None):
+    """tri.js:155-221"""
+    return _tri_solve(False, L, Y, "tril_solve(L,Y)", device)
+
+
+def triu_solve(U, Y, device=None):
+    """tri.js:224-290"""
+    return _tri_solve(True, U, Y, "triu_solve(U,Y)", device)
+
+
+def lu_solve(LU, P, y=None, device=None):
+    """lu.js:84-177; accepts lu_solve((LU,P), y) like the reference (:86)."""
+    if y is None:
+        y = P
+        LU, P = LU
+    LU = _asarray(LU, "lu_solve")
+    P = np.ascontiguousarray(np.asarray(P), dtype=np.int32)
+    y = _asarray(y, "lu_solve")
+    if LU.ndim < 2:
+        raise ValueError("LU must be at least 2D.")
+    if P.ndim < 1:
+        raise ValueError("P must be at least 1D.")
+    if y.ndim < 2:
+        raise ValueError("y must be at least 2D.")
+    N = LU.shape[-2]
+    I, J = y.shape[-2:]
+    if LU.shape[-1] != N:
+        raise ValueError("Last two dimensions of LU must be quadratic.")
+    if N != I:
+        raise ValueError("LU and y don't match.")
+    if P.shape[-1] != N:
+        raise ValueError("LU and P don't match.")
+    try:
+        lead = np.broadcast_shapes(LU.shape[:-2], y.shape[:-2])
+    except ValueError:
+        raise ValueError("LU and y are not broadcast-compatible.")
+    try:
+        lead = np.broadcast_shapes(lead, P.shape[:-1])
+    except ValueError:
+        raise ValueError("P is not broadcast-compatible.")
+    X = np.empty(tuple(lead) + (N, J))
+    h = _lib.handle(device)
+    for cnt, (oLU, oP, oY), (sLU, sP, sY), b0 in _bcast_groups_n(tuple(lead), [LU.shape[:-2], P.shape[:-1], y.shape[:-2]], [N * N, N, N * J]):
+        _lib.check(h.lib.nd4hip_dgetrs_batched(h.ptr, cnt, N, J, _off(LU, oLU), sLU, _off(P, oP, 4), sP, _off(y, oY), sY, _off(X, b0 * N * J)))
+    return X

@@ -40,6 +40,9 @@ def lib():
         L.nd4o_qr_decomp_full.argtypes = [_i64, _i64, _i64, _dp, _dp, _dp]
         L.nd4o_qr_decomp.argtypes = [_i64, _i64, _i64, _dp, _dp, _dp]
         L.nd4o_lu_decomp.argtypes = [_i64, _i64, _dp, _dp, _ip]
+        L.nd4o_tril_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
+        L.nd4o_triu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
+        L.nd4o_lu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _ip, _i64, _dp, _i64, _dp]
         L.nd4o_svd_jac_2sided.restype = ctypes.c_int
         L.nd4o_svd_jac_2sided.argtypes = [_i64, _i64, _dp, _dp, _dp, _dp]
         _lib = L
@@ -129,3 +132,40 @@ def svd_jac_2sided(a):
     sv = np.empty(a.shape[:-1])
     sweeps = lib().nd4o_svd_jac_2sided(batch, N, _d(a), _d(u), _d(sv), _d(v))
     return u, sv, v, sweeps
+
+
+def _bcast3(lead_shapes):
+    return np.broadcast_shapes(*lead_shapes)
+
+
+def _tri_solve(fn, T, Y):
+    T, Y = _f64(T), _f64(Y)
+    M, O = Y.shape[-2:]
+    lead = _bcast3([T.shape[:-2], Y.shape[:-2]])
+    Tb = np.ascontiguousarray(np.broadcast_to(T, lead + (M, M)))
+    X = np.ascontiguousarray(np.broadcast_to(Y, lead + (M, O))).copy()
+    batch = int(np.prod(lead, dtype=np.int64))
+    fn(batch, M, O, _d(Tb), M * M, _d(X))
+    return X
+
+
+def tril_solve(L, Y):
+    return _tri_solve(lib().nd4o_tril_solve, L, Y)
+
+
+def triu_solve(U, Y):
+    return _tri_solve(lib().nd4o_triu_solve, U, Y)
+
+
+def lu_solve(LU, P, Y):
+    LU, Y = _f64(LU), _f64(Y)
+    P = np.ascontiguousarray(P, dtype=np.int32)
+    N, J = Y.shape[-2:]
+    lead = _bcast3([LU.shape[:-2], P.shape[:-1], Y.shape[:-2]])
+    LUb = np.ascontiguousarray(np.broadcast_to(LU, lead + (N, N)))
+    Pb = np.ascontiguousarray(np.broadcast_to(P, lead + (N,)))
+    Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
+    X = np.empty(lead + (N, J))
+    batch = int(np.prod(lead, dtype=np.int64))
+    lib().nd4o_lu_solve(batch, N, J, _d(LUb), N * N, _i(Pb), N, _d(Yb), N * J, _d(X))
+    return X

@@ -166,6 +166,40 @@ if (what === 'small') {
   caseMatmul('edge_matmul_1x1', 56, 57, [1, 1], [1, 1]);
 }
 
+if (what === 'solve') {
+  /* SURVEY §8f N1: the solve-side consumers of the path (lu.js:84-177, tri.js:155-290) */
+  const triangle = (seed, shape, upper) => {      // well-conditioned triangle: off-diagonal / 4, |diag| in [2, 3)
+    const M = shape[shape.length - 1], a = fill(seed, shape.reduce((x, y) => x * y, 1));
+    for (let o = 0; o < a.length; o += M * M)
+      for (let i = 0; i < M; i++) for (let j = 0; j < M; j++) {
+        const k = o + i * M + j;
+        if (i === j) a[k] += a[k] >= 0 ? 2 : -2;
+        else if (upper ? j < i : j > i) a[k] = 0; else a[k] *= 0.25;
+      }
+    return a;
+  };
+  const caseLuSolve = (name, seedA, shapeA, seedY, shapeY) => {
+    const [LU, P] = nd.la.lu_decomp(NDA(shapeA, fill(seedA, shapeA.reduce((x, y) => x * y, 1))));
+    const X = nd.la.lu_solve(LU, P, NDA(shapeY, fill(seedY, shapeY.reduce((x, y) => x * y, 1))));
+    record(name, {op: 'lu_solve', seedA, shapeA, seedY, shapeY}, {X: [X.data, Array.from(X.shape)]});
+  };
+  const caseTri = (name, fn, seedT, shapeT, seedY, shapeY) => {
+    const X = nd.la[fn](NDA(shapeT, triangle(seedT, shapeT, fn === 'triu_solve')), NDA(shapeY, fill(seedY, shapeY.reduce((x, y) => x * y, 1))));
+    record(name, {op: fn, seedT, shapeT, seedY, shapeY}, {X: [X.data, Array.from(X.shape)]});
+  };
+  caseLuSolve('solve_lu_40', 61, [40, 40], 62, [40, 7]);
+  caseLuSolve('solve_lu_bcast', 63, [3, 12, 12], 64, [12, 5]);
+  caseLuSolve('solve_lu_batch', 65, [2, 33, 33], 66, [2, 33, 1]);
+  caseLuSolve('solve_lu_1x1', 67, [1, 1], 68, [1, 3]);
+  caseLuSolve('solve_lu_130', 69, [130, 130], 70, [130, 130]);
+  caseTri('solve_triu_30', 'triu_solve', 71, [30, 30], 72, [30, 4]);
+  caseTri('solve_tril_30', 'tril_solve', 73, [30, 30], 74, [30, 4]);
+  caseTri('solve_triu_bcast', 'triu_solve', 75, [2, 10, 10], 76, [10, 3]);
+  caseTri('solve_tril_bcast', 'tril_solve', 77, [17, 17], 78, [3, 17, 2]);
+  caseTri('solve_triu_100', 'triu_solve', 79, [100, 100], 80, [100, 65]);
+  caseTri('solve_tril_100', 'tril_solve', 81, [100, 100], 82, [100, 65]);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

@@ -195,6 +195,40 @@ void nd4o_lu_decomp(int64_t batch, int64_t N, const double* A, double* LU, int32
   }
 }
 
+/* ------------------------------------------------------------------ triangular solves (tri.js) */
+static void tril_solve1(int64_t M, int64_t N, int64_t O, const double* L, double* X) {        /* tri.js:61-70 */
+  for (int64_t i = 0; i < M; i++) {
+    for (int64_t k = 0; k < i; k++)
+      for (int64_t j = 0; j < O; j++) X[O * i + j] -= L[N * i + k] * X[O * k + j];
+    for (int64_t j = 0; j < O; j++) X[O * i + j] /= L[N * i + i];
+  }
+}
+static void triu_solve1(int64_t M, int64_t N, int64_t O, const double* U, double* X) {        /* tri.js:87-94 */
+  for (int64_t i = M; i-- > 0;)
+    for (int64_t j = O; j-- > 0;) {
+      for (int64_t k = M; --k > i;) X[O * i + j] -= U[N * i + k] * X[O * k + j];
+      X[O * i + j] /= U[N * i + i];
+    }
+}
+void nd4o_tril_solve(int64_t batch, int64_t M, int64_t O, const double* L, int64_t sL, double* X) {
+  for (int64_t b = 0; b < batch; b++) tril_solve1(M, M, O, L + b * sL, X + b * M * O);
+}
+void nd4o_triu_solve(int64_t batch, int64_t M, int64_t O, const double* U, int64_t sU, double* X) {
+  for (int64_t b = 0; b < batch; b++) triu_solve1(M, M, O, U + b * sU, X + b * M * O);
+}
+void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_t sLU, const int32_t* P, int64_t sP,
+                   const double* Y, int64_t sY, double* X) {
+  for (int64_t b = 0; b < batch; b++) {
+    const double* lu = LU + b * sLU; const int32_t* p = P + b * sP; const double* y = Y + b * sY; double* x = X + b * N * J;
+    for (int64_t i = 0; i < N; i++)                                          /* lu.js:131-136 */
+      for (int64_t j = 0; j < J; j++) x[J * i + j] = y[J * p[i] + j];
+    for (int64_t i = 0; i < N; i++)                                          /* lu.js:139-142 */
+      for (int64_t j = 0; j < J; j++)
+        for (int64_t k = 0; k < i; k++) x[i * J + j] -= lu[N * i + k] * x[k * J + j];
+    triu_solve1(N, N, J, lu, x);                                             /* lu.js:145 */
+  }
+}
+
 /* ------------------------------------------------------------------ two-sided Jacobi SVD */
 /* _svd_jac_utils.js:72-114 */
 static void svd_jac_angles(double S_pp, double S_pq, double S_qp, double S_qq,

@@ -43,6 +43,15 @@ void nd4o_qr_decomp(int64_t batch, int64_t M, int64_t N, const double* A, double
 /* src/la/lu.js:24-81  LU[batch,N,N], P[batch,N] (permutation vector: A[P[i],:] = (L*U)[i,:]) */
 void nd4o_lu_decomp(int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 
+/* src/la/tri.js:45-71 (_tril_solve) / :74-95 (_triu_solve) on [batch] M x M triangles (non-unit diagonal) and
+ * [batch] M x O right-hand sides, in place on X (X is initialised with Y by the caller). strideT = 0 broadcasts T. */
+void nd4o_tril_solve(int64_t batch, int64_t M, int64_t O, const double* L, int64_t strideL, double* X);
+void nd4o_triu_solve(int64_t batch, int64_t M, int64_t O, const double* U, int64_t strideU, double* X);
+/* src/la/lu.js:84-177 lu_solve core (:130-147): X = Y[P,:], forward substitution with the unit-lower part,
+ * _triu_solve with the upper part. strides in elements, 0 = broadcast. X [batch, N, J]. */
+void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU, const int32_t* P, int64_t strideP,
+                   const double* Y, int64_t strideY, double* X);
+
 /* src/la/svd_jac_2sided.js:30-144 (square input only; the rectangular pre-reduction :42-52 is
  * host-side composition) + _svd_jac_utils.js:72-114 (angles), :123-188 (post-processing).
  * U[batch,N,N], sv[batch,N], V[batch,N,N] (rows of V = right singular vectors). Returns sweeps. */

@@ -39,3 +39,16 @@ def make_input(seed, shape, family="dense"):
     for b in range(a.shape[0]):
         apply_family(family, a[b], seed + b)
     return a.reshape(shape)
+
+
+def triangle(seed, shape, upper):
+    """numpy twin of gen_golden.js `triangle`: off-diagonal / 4, |diag| in [2, 3) -> well conditioned."""
+    shape = tuple(shape)
+    M = shape[-1]
+    a = fill_uniform(seed, int(np.prod(shape))).reshape((-1, M, M))
+    for b in range(a.shape[0]):
+        d = np.diag(a[b]).copy()
+        d = d + np.where(d >= 0, 2.0, -2.0)
+        t = (np.triu(a[b], 1) if upper else np.tril(a[b], -1)) * 0.25
+        a[b] = t + np.diag(d)
+    return a.reshape(shape)

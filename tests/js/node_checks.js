@@ -35,6 +35,8 @@ if (mode === 'cpu') {
   assert.throws(() => la.matmul2(fill(1, [2, 2, 3]), fill(2, [3, 3, 2])), /broadcast-compatible/);
   assert.throws(() => la.qr_decomp([1, 2, 3]), /at least 2/);
   assert.throws(() => la.lu_decomp([[1, 2, 3], [4, 5, 6]]), /quadratic/);
+  assert.throws(() => la.triu_solve([[1, 2, 3], [4, 5, 6]], [[1], [2]]), /must be quadratic/);
+  assert.throws(() => la.lu_solve([[1, 0], [0, 1]], new la.NDArray(Int32Array.of(2), Int32Array.of(0, 1)), [[1], [2], [3]]), /LU and y don't match/);
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
   assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
   assert.ok(/gfx950/.test(la.version()));
@@ -74,6 +76,14 @@ if (mode === 'gpu') {
     let d = 0; for (let i = 0; i < ref.length; i++) d = Math.max(d, Math.abs(sv.data[i] - ref[i]));
     assert.ok(d <= 1e-12 * ref[0]); assert.deepStrictEqual(Array.from(U.shape), [96, 96]); assert.deepStrictEqual(Array.from(V.shape), [96, 96]);
     assert.ok(la.last_svd_info.sweeps > 0); }
+  { const m = man.solve_lu_bcast, A = fill(m.seedA, m.shapeA), Y = fill(m.seedY, m.shapeY);
+    const X = la.lu_solve(la.lu_decomp(A), Y), ref = npy('solve_lu_bcast', 'X');
+    assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-11); }
+  { const m = man.solve_tril_bcast, T = fill(m.seedT, m.shapeT), M = m.shapeT[m.shapeT.length - 1];
+    for (let i = 0; i < M; i++) for (let j = 0; j < M; j++) { const k = i * M + j;
+      if (i === j) T.data[k] += T.data[k] >= 0 ? 2 : -2; else if (j > i) T.data[k] = 0; else T.data[k] *= 0.25; }
+    const X = la.tril_solve(T, fill(m.seedY, m.shapeY)), ref = npy('solve_tril_bcast', 'X');
+    assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-12); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }

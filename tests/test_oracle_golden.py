@@ -112,3 +112,24 @@ def test_big_configs_sampled(golden):
     assert np.array_equal(p, g["P"])
     assert np.array_equal(lu.reshape(-1)[g["LUidx"]], g["LUval"])
     assert np.isclose(np.linalg.norm(lu), g.froLU, rtol=1e-14)
+
+
+# ---- solve-side consumers (lu.js:84-177, tri.js:45-290) ----
+from families import triangle  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_cases(op="lu_solve"))
+def test_lu_solve_bit_exact(golden, name):
+    g = golden(name)
+    lu, p = oracle.lu_decomp(rng.matrix(g.seedA, *g.shapeA))
+    x = oracle.lu_solve(lu, p, rng.matrix(g.seedY, *g.shapeY))
+    assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+@pytest.mark.parametrize("name", golden_cases(op="triu_solve") + golden_cases(op="tril_solve"))
+def test_tri_solve_bit_exact(golden, name):
+    g = golden(name)
+    upper = g.op == "triu_solve"
+    t = triangle(g.seedT, g.shapeT, upper)
+    x = (oracle.triu_solve if upper else oracle.tril_solve)(t, rng.matrix(g.seedY, *g.shapeY))
+    assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
