@@ -90,7 +90,7 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     f = 21.0 * n ** 3 * B

@@ -40,8 +40,11 @@ def svd_decomp_sharded(A_local, batch_total, group=None, compute=None):
         failed = 1.0
         raise
     finally:
+        # RCCL moves device tensors directly; any other backend (gloo: CPU tests, single-GPU rehearsal) is staged
+        # through host memory
+        cdev = A_local.device if (world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
         health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0), failed],
-                              dtype=torch.float64, device=A_local.device)
+                              dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(health, op=dist.ReduceOp.MAX, group=group)               # R1
     if world > 1:
@@ -50,11 +53,11 @@ def svd_decomp_sharded(A_local, batch_total, group=None, compute=None):
         L = sv.shape[-1]
         sizes = shard_sizes(batch_total, world)
         pad = max(sizes)
-        mine = torch.zeros((pad, L), dtype=sv.dtype, device=sv.device)
+        mine = torch.zeros((pad, L), dtype=sv.dtype, device=cdev)
         mine[: sv.shape[0]] = sv
-        buf = torch.empty((world * pad, L), dtype=sv.dtype, device=sv.device)
+        buf = torch.empty((world * pad, L), dtype=sv.dtype, device=cdev)
         dist.all_gather_into_tensor(buf, mine, group=group)                           # R2
-        sv_all = torch.cat([buf[r * pad: r * pad + sizes[r]] for r in range(world)])
+        sv_all = torch.cat([buf[r * pad: r * pad + sizes[r]] for r in range(world)]).to(sv.device)
     else:
         sv_all = sv
     return U, sv_all, V, {"max_sweeps": int(health[0].item()), "max_offnorm": health[1].item(), "failed": bool(health[2].item())}
