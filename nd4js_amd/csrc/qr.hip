@@ -24,6 +24,7 @@
 #include "nd4hip_internal.h"
 #include "dpp.h"
 #include <type_traits>
+#include <cfloat>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -493,6 +494,32 @@ void launch_panel_row(nd4hip_handle* h, int batch, double* W, int M, long ld, lo
                       double* T, long sT, double* taus, long sTau, int j0, int nb) {
   hipLaunchKernelGGL((qr_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
 }
+// ---- exact power-of-two normalisation: the reference's Givens kernel (_giv_rot.js:22-37) scales by max(|a|,|b|)
+// and never overflows; Householder squares the entries. Per matrix: e = 0 if 2^-400 <= max|a| <= 2^400, else the
+// exponent that brings max|a| to [1,2); the work copy is multiplied by 2^-e and R by 2^e (both exact).
+__global__ __launch_bounds__(256) void qr_amax(const double* __restrict__ Am, long n_per, unsigned long long* __restrict__ amax_bits) {
+  const double* A = Am + blockIdx.y * n_per;
+  double mx = 0.0;
+  for (long i = blockIdx.x * 256l + threadIdx.x; i < n_per; i += (long)gridDim.x * 256) { const double v = fabs(A[i]); mx = (v > mx) ? v : mx; }   // NaN ignored
+  mx = nd4dpp::wave_max(mx);
+  // the bit pattern of a non-negative double is monotone: an integer max is order independent (deterministic)
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(amax_bits + blockIdx.y, (unsigned long long)__double_as_longlong(mx));
+}
+__device__ __forceinline__ int qr_scale_exponent(unsigned long long bits) {
+  const double m = __longlong_as_double((long long)bits);
+  int e = 0;
+  if (m > 0.0 && m < DBL_MAX * 2.0) { int ex; (void)frexp(m, &ex); if (ex > 400 || ex < -400) e = ex - 1; }
+  return e;
+}
+__global__ __launch_bounds__(256) void qr_scale_apply(const double* __restrict__ src, double* __restrict__ dst, long n_per,
+                                                       const unsigned long long* __restrict__ amax_bits, int sign) {
+  const int e = sign * qr_scale_exponent(amax_bits[blockIdx.y]);
+  const long i = blockIdx.x * 256l + threadIdx.x;
+  if (i >= n_per) return;
+  const double v = src[blockIdx.y * n_per + i];
+  if (e != 0 || src != dst) dst[blockIdx.y * n_per + i] = (e == 0) ? v : ldexp(v, e);
+}
+
 template <int R, bool REG>
 void launch_panel(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
                   double* T, long sT, double* taus, long sTau, int j0, int nb) {
@@ -543,7 +570,7 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   ws.sW2 = ws.sChunk;
   const long sWork = tall ? (long)M * N : 0;
   size_t doubles = (size_t)batch * (ws.sV + ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
-  size_t bytes = doubles * sizeof(double) + (size_t)batch * L * sizeof(int) + 64;
+  size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + 64;
   void* p = nullptr;
   Nd4WsScope scope(h);
   ND4_TRY(nd4_ws_alloc(h, bytes, &p));
@@ -559,7 +586,13 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   // working matrix: R's buffer when it has A's shape (M <= N), a workspace copy when tall
   double* W = tall ? ws.work : R;
   const long ld = N, sW = (long)M * N;
-  ND4_HIP(hipMemcpyAsync(W, A, sizeof(double) * batch * sW, hipMemcpyDeviceToDevice, h->stream));
+  unsigned long long* exps = reinterpret_cast<unsigned long long*>(ws.flips + (((size_t)batch * L + 1) & ~size_t(1)));   // max|a| bits per matrix
+  ND4_HIP(hipMemsetAsync(exps, 0, sizeof(unsigned long long) * batch, h->stream));
+  {
+    long nblk = (sW + 256 * 16 - 1) / (256 * 16); if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(qr_amax, dim3((unsigned)nblk, (unsigned)batch), dim3(256), 0, h->stream, A, sW, exps);
+  }
+  hipLaunchKernelGGL(qr_scale_apply, dim3((unsigned)((sW + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, A, W, sW, exps, -1);
   ND4_HIP(hipMemsetAsync(ws.V, 0, sizeof(double) * (size_t)batch * ws.sV, h->stream));
 
   // ---- factorisation: panels left to right ----
@@ -583,6 +616,10 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   // ---- R out (tall: top N x N of the work matrix; else already in place, lower part zeroed by the panels) ----
   if (tall) ND4_TRY(nd4_copy_matrix(h, L, N, W, ld, R, N, batch, sW, (long)L * N));
 
+  {   // undo the power-of-two normalisation on R (exact; a no-op when the exponent is 0)
+    const long nR = (long)L * N;
+    hipLaunchKernelGGL(qr_scale_apply, dim3((unsigned)((nR + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, R, R, nR, exps, +1);
+  }
   // ---- Q = H_0 H_1 ... H_{p-1} [I; 0]: block reflectors applied backwards ----
   const long sQ = (long)M * L;
   ND4_TRY(nd4_set_identity(h, M, L, Q, L, batch, sQ));

@@ -112,3 +112,13 @@ def test_c3_2048_against_reference(la, golden):
     assert abs(np.linalg.norm(q) - g.froQ) <= 1e-11 * g.froQ
     assert np.abs(q @ r - a).max() <= 1e-11
     assert np.abs(q.T @ q - np.eye(N)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("scale", [1e200, 1e-200, 3e150])
+def test_extreme_scales_like_the_scaled_givens(la, scale):
+    """_giv_rot_qr scales by max(|a|,|b|) (_giv_rot.js:22-37): the reference factors 1e200*A without overflow."""
+    a = rng.matrix(970, 40, 40) * scale
+    q, r = la.qr_decomp(a)
+    rq, rr = oracle.qr_decomp(a)
+    assert np.isfinite(r).all() and np.isfinite(q).all()
+    assert relerr(r / scale, rr / scale) <= 1e-12 and relerr(q, rq) <= 1e-12
