@@ -62,10 +62,11 @@ __device__ __forceinline__ void gram_accumulate(d4 (&acc)[4][4], const double* c
     d2 f[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) f[t] = (c < N) ? *reinterpret_cast<const d2*>(rp[t] + c) : d2{0.0, 0.0};
+    // the Gram matrix is symmetric: only the 10 tiles with j >= i are computed (mirrored in gram_reduce_lds)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = i; j < 4; j++) {
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].x, f[j].x, acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].y, f[j].y, acc[i][j], 0, 0, 0);
       }
@@ -80,11 +81,14 @@ __device__ __forceinline__ void gram_reduce_lds(double (*G)[LDG], const d4 (&acc
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = i; j < 4; j++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            double* d = &G[i * 16 + fk + 4 * r][j * 16 + fx];
-            *d = (w == 0) ? acc[i][j][r] : *d + acc[i][j][r];
+            const int row = i * 16 + fk + 4 * r, col = j * 16 + fx;
+            double* d = &G[row][col];
+            const double v = (w == 0) ? acc[i][j][r] : *d + acc[i][j][r];
+            *d = v;
+            if (w == 3 && j > i) G[col][row] = v;                  // mirror the off-diagonal tiles once the sum is final
           }
     }
     __syncthreads();
