@@ -99,6 +99,28 @@ int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_diag, int64_t
 int nd4hip_dtrsm_batched    (nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
                              const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X);
 
+/* ---- qr_lstsq: replaces src/la/qr.js:186-273 -------------------------------------
+ * X [batch,I,J] = R[0:L,0:L]^-1 (Q^T Y)[0:L,:], L = min(M,I), rows L..I-1 zero; Q [batch,N,M], R [batch,M,I]
+ * (as returned by dgeqrf_q for an N x I system: M = min(N,I)), Y [batch,N,J]. I > N is refused like qr.js:209.
+ * strides in elements, 0 = broadcast. One TN GEMM + one blocked triangular solve on the device. */
+int nd4hip_dqrls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                             const double* Q, int64_t strideQ, const double* R, int64_t strideR,
+                             const double* Y, int64_t strideY, double* X);
+int nd4hip_dqrls_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                             const double* Q, int64_t strideQ, const double* R, int64_t strideR,
+                             const double* Y, int64_t strideY, double* X);
+
+/* ---- svd_lstsq / svd_solve: replace src/la/svd.js:66-228 ---------------------------------------------
+ * X [batch,I,J] = V[0:r,:]^T diag(1/sv[0:r]) U[:,0:r]^T Y with r = first index with |sv_r| <= sqrt(eps)|sv_0|
+ * (svd_rank, svd.js:31-63), U [batch,N,M], sv [batch,M], V [batch,M,I], Y [batch,N,J]. The host form
+ * refuses non-finite singular values (svd.js:171-172, ND4HIP_ERR_ARG); the _dev form does not look. */
+int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                              const double* U, int64_t strideU, const double* sv, int64_t strideSv,
+                              const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X);
+int nd4hip_dsvdls_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                              const double* U, int64_t strideU, const double* sv, int64_t strideSv,
+                              const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X);
+
 /* ---- qr_decomp: replaces src/la/qr.js:80-145 / qr_decomp_full :27-77 ----------------------------
  * A [batch,M,N] -> Q [batch,M,L], R [batch,L,N], L = min(M,N); blocked Householder with the
  * reference's Givens sign convention restored (R_jj >= 0 wherever a column had something to

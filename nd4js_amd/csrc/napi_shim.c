@@ -30,6 +30,9 @@ static int (*p_dgemm)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, const 
 static int (*p_dgetrf)(nd4hip_handle*, int64_t, int64_t, const double*, double*, int32_t*);
 static int (*p_dgeqrf)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*);
 static int (*p_dgesvdj)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*, int*, double*);
+static int (*p_dqrls)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t, double*);
+static int (*p_dsvdls)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t,
+                       const double*, int64_t, double*);
 static int (*p_dgetrs)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const int32_t*, int64_t, const double*, int64_t, double*);
 static int (*p_dtrsm)(nd4hip_handle*, int, int, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
 
@@ -66,6 +69,8 @@ static int load_library(void) {
   SYM(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
   SYM(p_dgesvdj, "nd4hip_dgesvdj_batched");
   SYM(p_dgetrs, "nd4hip_dgetrs_batched");
+  SYM(p_dqrls, "nd4hip_dqrls_batched");
+  SYM(p_dsvdls, "nd4hip_dsvdls_batched");
   SYM(p_dtrsm, "nd4hip_dtrsm_batched");
 #undef SYM
   return 0;
@@ -224,6 +229,46 @@ static napi_value js_dtrsm(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* dqrls_batched(batch, N, M, I, J, Q, strideQ, R, strideR, Y, strideY, X)   (qr_lstsq, qr.js:186-273) */
+static napi_value js_dqrls(napi_env env, napi_callback_info info) {
+  size_t argc = 12; napi_value a[12];
+  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
+  NEED(argc == 12, "dqrls_batched: 12 arguments expected");
+  int64_t batch, N, M, I, J, sQ, sR, sY; void *Q, *R, *Y, *X; size_t nQ, nR, nY, nX;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &M) || get_i64(env, a[3], &I) || get_i64(env, a[4], &J) ||
+      get_ta(env, a[5], napi_float64_array, &Q, &nQ) || get_i64(env, a[6], &sQ) ||
+      get_ta(env, a[7], napi_float64_array, &R, &nR) || get_i64(env, a[8], &sR) ||
+      get_ta(env, a[9], napi_float64_array, &Y, &nY) || get_i64(env, a[10], &sY) ||
+      get_ta(env, a[11], napi_float64_array, &X, &nX)) return NULL;
+  NEED(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0 && sQ >= 0 && sR >= 0 && sY >= 0, "dqrls_batched: negative extent");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sQ + N * M) <= nQ && (size_t)((batch - 1) * sR + M * I) <= nR &&
+                      (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * I * J) <= nX), "dqrls_batched: buffer too small");
+  if (ensure_handle(env)) return NULL;
+  if (p_dqrls(g_handle, batch, N, M, I, J, (const double*)Q, sQ, (const double*)R, sR, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  return NULL;
+}
+/* dsvdls_batched(batch, N, M, I, J, U, strideU, sv, strideSv, V, strideV, Y, strideY, X)   (svd_lstsq, svd.js:100-228) */
+static napi_value js_dsvdls(napi_env env, napi_callback_info info) {
+  size_t argc = 14; napi_value a[14];
+  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
+  NEED(argc == 14, "dsvdls_batched: 14 arguments expected");
+  int64_t batch, N, M, I, J, sU, sS, sV, sY; void *U, *S, *V, *Y, *X; size_t nU, nS, nV, nY, nX;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &M) || get_i64(env, a[3], &I) || get_i64(env, a[4], &J) ||
+      get_ta(env, a[5], napi_float64_array, &U, &nU) || get_i64(env, a[6], &sU) ||
+      get_ta(env, a[7], napi_float64_array, &S, &nS) || get_i64(env, a[8], &sS) ||
+      get_ta(env, a[9], napi_float64_array, &V, &nV) || get_i64(env, a[10], &sV) ||
+      get_ta(env, a[11], napi_float64_array, &Y, &nY) || get_i64(env, a[12], &sY) ||
+      get_ta(env, a[13], napi_float64_array, &X, &nX)) return NULL;
+  NEED(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0 && sU >= 0 && sS >= 0 && sV >= 0 && sY >= 0, "dsvdls_batched: negative extent");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sU + N * M) <= nU && (size_t)((batch - 1) * sS + M) <= nS &&
+                      (size_t)((batch - 1) * sV + M * I) <= nV && (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * I * J) <= nX),
+       "dsvdls_batched: buffer too small");
+  if (ensure_handle(env)) return NULL;
+  if (p_dsvdls(g_handle, batch, N, M, I, J, (const double*)U, sU, (const double*)S, sS, (const double*)V, sV, (const double*)Y, sY, (double*)X) != 0)
+    THROW(env, p_last_error());
+  return NULL;
+}
+
 static void cleanup(void* arg) {
   (void)arg;
   if (g_handle && p_destroy) { p_destroy(g_handle); g_handle = NULL; }
@@ -238,6 +283,8 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgesvdj_batched", NULL, js_dgesvdj, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrs_batched", NULL, js_dgetrs, NULL, NULL, NULL, napi_default, NULL},
+    {"dqrls_batched", NULL, js_dqrls, NULL, NULL, NULL, napi_default, NULL},
+    {"dsvdls_batched", NULL, js_dsvdls, NULL, NULL, NULL, napi_default, NULL},
     {"dtrsm_batched", NULL, js_dtrsm, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);

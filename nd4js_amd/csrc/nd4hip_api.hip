@@ -1,6 +1,7 @@
 // extern "C" entry points of include/nd4hip.h: argument validation, the *_dev (device pointer) forms
 // and the host-pointer forms (H2D -> kernels -> D2H) that the N-API shim binds.
 #include "nd4hip_internal.h"
+#include <cmath>
 
 namespace {
 
@@ -157,6 +158,86 @@ extern "C" int nd4hip_dtrsm_batched(nd4hip_handle* h, int upper, int unit_diag, 
   ND4_TRY(dT.alloc(nT * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
   ND4_TRY(h2d(h, dT.p, T, nT * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
   ND4_TRY(nd4hip_dtrsm_batched_dev(h, upper, unit_diag, batch, M, J, (const double*)dT.p, strideT, (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228)
+extern "C" int nd4hip_dqrls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                                        const double* Q, int64_t strideQ, const double* R, int64_t strideR,
+                                        const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dqrls_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dqrls_batched: negative extent");
+  ND4_CHECK_ARG(I <= N, "qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.");      // qr.js:209
+  ND4_CHECK_ARG((strideQ == 0 || strideQ >= N * M) && (strideR == 0 || strideR >= M * I) && (strideY == 0 || strideY >= N * J),
+                "nd4hip_dqrls_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(X != nullptr, "nd4hip_dqrls_batched: NULL pointer");
+  if (N == 0 || M == 0) { ND4_HIP(hipMemsetAsync(X, 0, D * (size_t)(batch * I * J), h->stream)); return 0; }
+  ND4_CHECK_ARG(Q && R && Y, "nd4hip_dqrls_batched: NULL pointer");
+  return nd4_qrls(h, batch, N, M, I, J, Q, strideQ, R, strideR, Y, strideY, X);
+}
+extern "C" int nd4hip_dqrls_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                                    const double* Q, int64_t strideQ, const double* R, int64_t strideR,
+                                    const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dqrls_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dqrls_batched: negative extent");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nQ = (size_t)(strideQ ? (batch - 1) * strideQ + N * M : N * M);
+  const size_t nR = (size_t)(strideR ? (batch - 1) * strideR + M * I : M * I);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
+  const size_t nX = (size_t)(batch * I * J);
+  DevBuf dQ, dR, dY, dX;
+  ND4_TRY(dQ.alloc(nQ * D)); ND4_TRY(dR.alloc(nR * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  if (nQ) ND4_TRY(h2d(h, dQ.p, Q, nQ * D));
+  if (nR) ND4_TRY(h2d(h, dR.p, R, nR * D));
+  if (nY) ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dqrls_batched_dev(h, batch, N, M, I, J, (const double*)dQ.p, strideQ, (const double*)dR.p, strideR,
+                                   (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                                         const double* U, int64_t strideU, const double* sv, int64_t strideSv,
+                                         const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dsvdls_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dsvdls_batched: negative extent");
+  ND4_CHECK_ARG((strideU == 0 || strideU >= N * M) && (strideSv == 0 || strideSv >= M) && (strideV == 0 || strideV >= M * I) &&
+                (strideY == 0 || strideY >= N * J), "nd4hip_dsvdls_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(X != nullptr, "nd4hip_dsvdls_batched: NULL pointer");
+  if (N == 0 || M == 0) { ND4_HIP(hipMemsetAsync(X, 0, D * (size_t)(batch * I * J), h->stream)); return 0; }
+  ND4_CHECK_ARG(U && sv && V && Y, "nd4hip_dsvdls_batched: NULL pointer");
+  return nd4_svdls(h, batch, N, M, I, J, U, strideU, sv, strideSv, V, strideV, Y, strideY, X);
+}
+extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
+                                     const double* U, int64_t strideU, const double* sv, int64_t strideSv,
+                                     const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dsvdls_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dsvdls_batched: negative extent");
+  if (batch == 0 || I == 0 || J == 0) return 0;
+  const size_t nU = (size_t)(strideU ? (batch - 1) * strideU + N * M : N * M);
+  const size_t nS = (size_t)(strideSv ? (batch - 1) * strideSv + M : M);
+  const size_t nV = (size_t)(strideV ? (batch - 1) * strideV + M * I : M * I);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
+  const size_t nX = (size_t)(batch * I * J);
+  if (M > 0) {
+    ND4_CHECK_ARG(sv != nullptr, "nd4hip_dsvdls_batched: NULL pointer");
+    for (size_t i = 0; i < nS; i++) ND4_CHECK_ARG(std::isfinite(sv[i]), "svd_solve(): NaN or Infinity encountered.");   // svd.js:171-172
+  }
+  ND4_HIP(hipSetDevice(h->device));
+  DevBuf dU, dS, dV, dY, dX;
+  ND4_TRY(dU.alloc(nU * D)); ND4_TRY(dS.alloc(nS * D)); ND4_TRY(dV.alloc(nV * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  if (nU) ND4_TRY(h2d(h, dU.p, U, nU * D));
+  if (nS) ND4_TRY(h2d(h, dS.p, sv, nS * D));
+  if (nV) ND4_TRY(h2d(h, dV.p, V, nV * D));
+  if (nY) ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dsvdls_batched_dev(h, batch, N, M, I, J, (const double*)dU.p, strideU, (const double*)dS.p, strideSv,
+                                    (const double*)dV.p, strideV, (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
   ND4_HIP(hipStreamSynchronize(h->stream));
   return 0;

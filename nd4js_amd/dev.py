@@ -145,3 +145,47 @@ def tri_solve(T, Y, upper, unit_diag=False):
     _lib.check(h.lib.nd4hip_dtrsm_batched_dev(h.ptr, int(bool(upper)), int(bool(unit_diag)), b, M, J, _p(T), M * M if b > 1 else 0,
                                               _p(Y), M * J if b > 1 else 0, _p(X)))
     return X
+
+
+def qr_lstsq(Q, R, Y):
+    """device-resident qr_lstsq (qr.js:186-273): Q [..., N, M], R [..., M, I], Y [..., N, J] with equal leading dims"""
+    _chk(Q, "Q"), _chk(R, "R"), _chk(Y, "Y")
+    N, M = Q.shape[-2:]
+    I, J = R.shape[-1], Y.shape[-1]
+    if N != Y.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and y don't match.")
+    if M != R.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and R don't match.")
+    if I > N:
+        raise ValueError("qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.")
+    lead = tuple(Y.shape[:-2])
+    if tuple(Q.shape[:-2]) != lead or tuple(R.shape[:-2]) != lead:
+        raise ValueError("Q, R, y are not broadcast-compatible.")      # general broadcasting: host wrapper (la.py)
+    X = torch.empty(lead + (I, J), dtype=torch.float64, device=Y.device)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dqrls_batched_dev(h.ptr, b, N, M, I, J, _p(Q), N * M if b > 1 else 0, _p(R), M * I if b > 1 else 0,
+                                              _p(Y), N * J if b > 1 else 0, _p(X)))
+    return X
+
+
+def svd_lstsq(U, sv, V, Y):
+    """device-resident svd_lstsq (svd.js:100-228); singular values are not checked for NaN/Inf here (no host read-back)"""
+    _chk(U, "U"), _chk(sv, "sv"), _chk(V, "V"), _chk(Y, "Y")
+    N, M = U.shape[-2:]
+    I, J = V.shape[-1], Y.shape[-1]
+    if N != Y.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and y don't match.")
+    if M != sv.shape[-1]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and sv don't match.")
+    if M != V.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): V and sv don't match.")
+    lead = tuple(Y.shape[:-2])
+    if tuple(U.shape[:-2]) != lead or tuple(V.shape[:-2]) != lead or tuple(sv.shape[:-1]) != lead:
+        raise ValueError("svd_lstsq(U,sv,V, y): U,sv,V,y not broadcast-compatible.")
+    X = torch.empty(lead + (I, J), dtype=torch.float64, device=Y.device)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dsvdls_batched_dev(h.ptr, b, N, M, I, J, _p(U), N * M if b > 1 else 0, _p(sv), M if b > 1 else 0,
+                                               _p(V), M * I if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
+    return X

@@ -286,6 +286,68 @@ function makeLa(NDA, fallback) {
       native().dgetrs_batched(cnt, N, J, LUd.subarray(oLU), sLU, P.data.subarray(oP), sP, yd.subarray(oY), sY, X.subarray(b0 * N * J));
     return new NDA(Int32Array.from([...lead, N, J]), X);
   };
+
+  /* ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ---- */
+  la.qr_lstsq = function qr_lstsq(Q, R, y) {
+    if (undefined == y) { y = R; [Q, R] = Q; }
+    Q = asarray(Q); if (Q.ndim < 2) throw new Error('qr_lstsq(Q,R,y): Q.ndim must be at least 2.');
+    R = asarray(R); if (R.ndim < 2) throw new Error('qr_lstsq(Q,R,y): R.ndim must be at least 2.');
+    y = asarray(y); if (y.ndim < 2) throw new Error('qr_lstsq(Q,R,y): y.ndim must be at least 2.');
+    const N = Q.shape[Q.ndim - 2], M = Q.shape[Q.ndim - 1], I = R.shape[R.ndim - 1], J = y.shape[y.ndim - 1];
+    if (N != y.shape[y.ndim - 2]) throw new Error("qr_lstsq(Q,R,y): Q and y don't match.");
+    if (M != R.shape[R.ndim - 2]) throw new Error("qr_lstsq(Q,R,y): Q and R don't match.");
+    if (I > N) throw new Error('qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.');
+    if (!gpuOk(Q) || !gpuOk(R) || !gpuOk(y)) {
+      if (fallback && fallback.qr_lstsq) return fallback.qr_lstsq(Q, R, y);
+      throw new Error('nd4hip.qr_lstsq: dtype is not accelerated.');
+    }
+    const lQ = Array.from(Q.shape.subarray(0, Q.ndim - 2)), lR = Array.from(R.shape.subarray(0, R.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
+    const lead = bcastLead([lQ, lR, lY], 'Q, R, y are not broadcast-compatible.');
+    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * I * J), Qd = f64(Q), Rd = f64(R), yd = f64(y);
+    for (const [cnt, [oQ, oR, oY], [sQ, sR, sY], b0] of bcastGroupsN(lead, [lQ, lR, lY], [N * M, M * I, N * J]))
+      native().dqrls_batched(cnt, N, M, I, J, Qd.subarray(oQ), sQ, Rd.subarray(oR), sR, yd.subarray(oY), sY, X.subarray(b0 * I * J));
+    return new NDA(Int32Array.from([...lead, I, J]), X);
+  };
+
+  la.svd_lstsq = function svd_lstsq(U, sv, V, y) {
+    if (y == undefined) {
+      if (V != undefined) throw new Error('svd_lstsq(Q,R,P, y): Either 2 ([Q,R,P], y) or 4 arguments (Q,R,P, y) expected.');
+      y = sv; [U, sv, V] = U;
+    }
+    U = asarray(U); if (U.ndim < 2) throw new Error('svd_lstsq(U,sv,V, y): U.ndim must be at least 2.');
+    sv = asarray(sv); if (sv.ndim < 1) throw new Error('svd_lstsq(U,sv,V, y): sv.ndim must be at least 1.');
+    V = asarray(V); if (V.ndim < 2) throw new Error('svd_lstsq(U,sv,V, y): V.ndim must be at least 2.');
+    y = asarray(y); if (y.ndim < 2) throw new Error('svd_lstsq(U,sv,V, y): y.ndim must be at least 2.');
+    const N = U.shape[U.ndim - 2], M = U.shape[U.ndim - 1], I = V.shape[V.ndim - 1], J = y.shape[y.ndim - 1];
+    if (N !== y.shape[y.ndim - 2]) throw new Error("svd_lstsq(U,sv,V, y): U and y don't match.");
+    if (M !== sv.shape[sv.ndim - 1]) throw new Error("svd_lstsq(U,sv,V, y): U and sv don't match.");
+    if (M !== V.shape[V.ndim - 2]) throw new Error("svd_lstsq(U,sv,V, y): V and sv don't match.");
+    if (!gpuOk(U) || !gpuOk(sv) || !gpuOk(V) || !gpuOk(y)) {
+      if (fallback && fallback.svd_lstsq) return fallback.svd_lstsq(U, sv, V, y);
+      throw new Error('nd4hip.svd_lstsq: dtype is not accelerated.');
+    }
+    const lU = Array.from(U.shape.subarray(0, U.ndim - 2)), lS = Array.from(sv.shape.subarray(0, sv.ndim - 1)),
+          lV = Array.from(V.shape.subarray(0, V.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
+    const lead = bcastLead([lU, lV, lY, lS], 'svd_lstsq(U,sv,V, y): U,sv,V,y not broadcast-compatible.');
+    const svd = f64(sv);
+    for (let i = 0; i < svd.length; i++) if (!isFinite(svd[i])) throw new Error('svd_solve(): NaN or Infinity encountered.');   // svd.js:171-172
+    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * I * J), Ud = f64(U), Vd = f64(V), yd = f64(y);
+    for (const [cnt, [oU, oS, oV, oY], [sU, sS, sV, sY], b0] of bcastGroupsN(lead, [lU, lS, lV, lY], [N * M, M, M * I, N * J]))
+      native().dsvdls_batched(cnt, N, M, I, J, Ud.subarray(oU), sU, svd.subarray(oS), sS, Vd.subarray(oV), sV, yd.subarray(oY), sY, X.subarray(b0 * I * J));
+    return new NDA(Int32Array.from([...lead, I, J]), X);
+  };
+
+  /* svd.js:66-97: the reference's singularity loop (`for( let r; r < N; r++ )`, :85) never executes, so apart from the
+     squareness check svd_solve IS svd_lstsq; mirrored as such. */
+  la.svd_solve = function svd_solve(U, sv, V, y) {
+    if (y == undefined) {
+      if (V != undefined) throw new Error('svd_lstsq(Q,R,P, y): Either 2 ([Q,R,P], y) or 4 arguments (Q,R,P, y) expected.');
+      y = sv; [U, sv, V] = U;
+    }
+    U = asarray(U); sv = asarray(sv); V = asarray(V);
+    if (U.shape[U.ndim - 2] !== V.shape[V.ndim - 1]) throw new Error('rrqr_solve(Q,R,P, y): System not square.');
+    return la.svd_lstsq(U, sv, V, y);
+  };
   return la;
 }
 
@@ -296,7 +358,8 @@ function install(nd) {
   if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp,
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
-                    lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve};
+                    lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
+                    qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

@@ -282,3 +282,98 @@ def lu_solve(LU, P, y=None, device=None):
     for cnt, (oLU, oP, oY), (sLU, sP, sY), b0 in _bcast_groups_n(tuple(lead), [LU.shape[:-2], P.shape[:-1], y.shape[:-2]], [N * N, N, N * J]):
         _lib.check(h.lib.nd4hip_dgetrs_batched(h.ptr, cnt, N, J, _off(LU, oLU), sLU, _off(P, oP, 4), sP, _off(y, oY), sY, _off(X, b0 * N * J)))
     return X
+
+
+def qr_lstsq(Q, R, y=None, device=None):
+    """qr.js:186-273; accepts qr_lstsq((Q,R), y) like the reference (:188)."""
+    if y is None:
+        y = R
+        Q, R = Q
+    Q, R, y = np.asarray(Q), np.asarray(R), np.asarray(y)
+    if Q.ndim < 2:
+        raise ValueError("qr_lstsq(Q,R,y): Q.ndim must be at least 2.")
+    if R.ndim < 2:
+        raise ValueError("qr_lstsq(Q,R,y): R.ndim must be at least 2.")
+    if y.ndim < 2:
+        raise ValueError("qr_lstsq(Q,R,y): y.ndim must be at least 2.")
+    Q, R, y = _asarray(Q, "qr_lstsq"), _asarray(R, "qr_lstsq"), _asarray(y, "qr_lstsq")
+    N, M = Q.shape[-2:]
+    I, J = R.shape[-1], y.shape[-1]
+    if N != y.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and y don't match.")
+    if M != R.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and R don't match.")
+    if I > N:
+        raise ValueError("qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.")
+    try:
+        lead = np.broadcast_shapes(Q.shape[:-2], R.shape[:-2], y.shape[:-2])
+    except ValueError:
+        raise ValueError("Q, R, y are not broadcast-compatible.")
+    X = np.empty(tuple(lead) + (I, J))
+    h = _lib.handle(device)
+    for cnt, (oQ, oR, oY), (sQ, sR, sY), b0 in _bcast_groups_n(tuple(lead), [Q.shape[:-2], R.shape[:-2], y.shape[:-2]], [N * M, M * I, N * J]):
+        _lib.check(h.lib.nd4hip_dqrls_batched(h.ptr, cnt, N, M, I, J, _off(Q, oQ), sQ, _off(R, oR), sR, _off(y, oY), sY, _off(X, b0 * I * J)))
+    return X
+
+
+def svd_rank(sv):
+    """svd.js:31-63: per matrix, the first r with |sv_r| <= sqrt(eps) |sv_0| (host side: sv is tiny)."""
+    sv = np.asarray(sv, dtype=np.float64)
+    if not np.all(np.isfinite(sv)):
+        raise ValueError("svd_rank(): NaN or Infinity encountered.")
+    N = sv.shape[-1]
+    small = np.abs(sv) <= np.sqrt(2.0 ** -52) * np.abs(sv[..., :1])
+    return np.where(small.any(axis=-1), small.argmax(axis=-1), N).astype(np.int32)
+
+
+def svd_lstsq(U, sv, V=None, y=None, device=None):
+    """svd.js:100-228; accepts svd_lstsq((U,sv,V), y) like the reference (:102-108)."""
+    if y is None:
+        if V is not None:
+            raise ValueError("svd_lstsq(Q,R,P, y): Either 2 ([Q,R,P], y) or 4 arguments (Q,R,P, y) expected.")
+        y = sv
+        U, sv, V = U
+    U, sv, V, y = np.asarray(U), np.asarray(sv), np.asarray(V), np.asarray(y)
+    if U.ndim < 2:
+        raise ValueError("svd_lstsq(U,sv,V, y): U.ndim must be at least 2.")
+    if sv.ndim < 1:
+        raise ValueError("svd_lstsq(U,sv,V, y): sv.ndim must be at least 1.")
+    if V.ndim < 2:
+        raise ValueError("svd_lstsq(U,sv,V, y): V.ndim must be at least 2.")
+    if y.ndim < 2:
+        raise ValueError("svd_lstsq(U,sv,V, y): y.ndim must be at least 2.")
+    U, sv, V, y = (_asarray(a, "svd_lstsq") for a in (U, sv, V, y))
+    N, M = U.shape[-2:]
+    I, J = V.shape[-1], y.shape[-1]
+    if N != y.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and y don't match.")
+    if M != sv.shape[-1]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and sv don't match.")
+    if M != V.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): V and sv don't match.")
+    try:
+        lead = np.broadcast_shapes(U.shape[:-2], V.shape[:-2], y.shape[:-2], sv.shape[:-1])
+    except ValueError:
+        raise ValueError("svd_lstsq(U,sv,V, y): U,sv,V,y not broadcast-compatible.")
+    if not np.all(np.isfinite(sv)):
+        raise ValueError("svd_solve(): NaN or Infinity encountered.")      # svd.js:171-172 (the reference's own wording)
+    X = np.empty(tuple(lead) + (I, J))
+    h = _lib.handle(device)
+    for cnt, (oU, oS, oV, oY), (sU, sS, sV, sY), b0 in _bcast_groups_n(
+            tuple(lead), [U.shape[:-2], sv.shape[:-1], V.shape[:-2], y.shape[:-2]], [N * M, M, M * I, N * J]):
+        _lib.check(h.lib.nd4hip_dsvdls_batched(h.ptr, cnt, N, M, I, J, _off(U, oU), sU, _off(sv, oS), sS, _off(V, oV), sV,
+                                               _off(y, oY), sY, _off(X, b0 * I * J)))
+    return X
+
+
+def svd_solve(U, sv, V=None, y=None, device=None):
+    """svd.js:66-97. The reference's singularity loop (`for( let r; r < N; r++ )`, :85) never executes, so apart from
+    the squareness check this IS svd_lstsq; mirrored as such."""
+    if y is None:
+        if V is not None:
+            raise ValueError("svd_lstsq(Q,R,P, y): Either 2 ([Q,R,P], y) or 4 arguments (Q,R,P, y) expected.")
+        y = sv
+        U, sv, V = U
+    if np.asarray(U).shape[-2] != np.asarray(V).shape[-1]:
+        raise ValueError("rrqr_solve(Q,R,P, y): System not square.")
+    return svd_lstsq(U, sv, V, y, device=device)

@@ -43,6 +43,9 @@ def lib():
         L.nd4o_tril_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_triu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_lu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _ip, _i64, _dp, _i64, _dp]
+        L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
+        L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
+        L.nd4o_svd_lstsq.restype = ctypes.c_int
         L.nd4o_svd_jac_2sided.restype = ctypes.c_int
         L.nd4o_svd_jac_2sided.argtypes = [_i64, _i64, _dp, _dp, _dp, _dp]
         _lib = L
@@ -168,4 +171,49 @@ def lu_solve(LU, P, Y):
     X = np.empty(lead + (N, J))
     batch = int(np.prod(lead, dtype=np.int64))
     lib().nd4o_lu_solve(batch, N, J, _d(LUb), N * N, _i(Pb), N, _d(Yb), N * J, _d(X))
+    return X
+
+
+def qr_lstsq(Q, R, Y):
+    """qr.js:186-273"""
+    Q, R, Y = _f64(Q), _f64(R), _f64(Y)
+    N, M = Q.shape[-2:]
+    I, J = R.shape[-1], Y.shape[-1]
+    if N != Y.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and y don't match.")
+    if M != R.shape[-2]:
+        raise ValueError("qr_lstsq(Q,R,y): Q and R don't match.")
+    if I > N:
+        raise ValueError("qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.")
+    lead = _bcast3([Q.shape[:-2], R.shape[:-2], Y.shape[:-2]])
+    Qb = np.ascontiguousarray(np.broadcast_to(Q, lead + (N, M)))
+    Rb = np.ascontiguousarray(np.broadcast_to(R, lead + (M, I)))
+    Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
+    X = np.empty(lead + (I, J))
+    lib().nd4o_qr_lstsq(int(np.prod(lead, dtype=np.int64)), N, M, I, J, _d(Qb), N * M, _d(Rb), M * I, _d(Yb), N * J, _d(X))
+    return X
+
+
+def svd_lstsq(U, sv, V, Y):
+    """svd.js:100-228"""
+    U, sv, V, Y = _f64(U), _f64(sv), _f64(V), _f64(Y)
+    N, M = U.shape[-2:]
+    I, J = V.shape[-1], Y.shape[-1]
+    if N != Y.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and y don't match.")
+    if M != sv.shape[-1]:
+        raise ValueError("svd_lstsq(U,sv,V, y): U and sv don't match.")
+    if M != V.shape[-2]:
+        raise ValueError("svd_lstsq(U,sv,V, y): V and sv don't match.")
+    lead = _bcast3([U.shape[:-2], sv.shape[:-1], V.shape[:-2], Y.shape[:-2]])
+    Ub = np.ascontiguousarray(np.broadcast_to(U, lead + (N, M)))
+    Sb = np.ascontiguousarray(np.broadcast_to(sv, lead + (M,)))
+    Vb = np.ascontiguousarray(np.broadcast_to(V, lead + (M, I)))
+    Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
+    X = np.empty(lead + (I, J))
+    tmp = np.empty(M * J)
+    rc = lib().nd4o_svd_lstsq(int(np.prod(lead, dtype=np.int64)), N, M, I, J, _d(Ub), N * M, _d(Sb), M, _d(Vb), M * I, _d(Yb), N * J,
+                              _d(X), _d(tmp))
+    if rc:
+        raise ValueError("svd_solve(): NaN or Infinity encountered.")
     return X

@@ -200,6 +200,39 @@ if (what === 'solve') {
   caseTri('solve_tril_100', 'tril_solve', 81, [100, 100], 82, [100, 65]);
 }
 
+if (what === 'lstsq') {
+  /* SURVEY §8f N1: qr_lstsq (qr.js:186-273) and svd_lstsq / svd_solve (svd.js:66-228). qr cases are keyed by seeds
+     (the oracle's qr_decomp is bit-identical); svd cases carry the reference's own U, sv, V as inputs. */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const caseQrLs = (name, seedA, shapeA, seedY, shapeY, full) => {
+    const [Q, R] = nd.la[full ? 'qr_decomp_full' : 'qr_decomp'](NDA(shapeA, fill(seedA, numel(shapeA))));
+    const X = nd.la.qr_lstsq(Q, R, NDA(shapeY, fill(seedY, numel(shapeY))));
+    record(name, {op: 'qr_lstsq', seedA, shapeA, seedY, shapeY, full: !!full}, {X: [X.data, Array.from(X.shape)]});
+  };
+  const caseSvdLs = (name, fn, seedA, shapeA, seedY, shapeY, rankDef) => {
+    const a = fill(seedA, numel(shapeA)), [M, N] = shapeA.slice(-2);
+    if (rankDef) for (let o = 0; o < a.length; o += M * N) for (let i = 0; i < M; i++) a[o + i * N + N - 1] = 2 * a[o + i * N];  // last column = 2 x first
+    const [U, sv, V] = nd.la.svd_decomp(NDA(shapeA, a));
+    const X = nd.la[fn](U, sv, V, NDA(shapeY, fill(seedY, numel(shapeY))));
+    record(name, {op: fn, seedA, shapeA, seedY, shapeY, rankDef: !!rankDef},
+           {U: [U.data, Array.from(U.shape)], sv: [sv.data, Array.from(sv.shape)], V: [V.data, Array.from(V.shape)], X: [X.data, Array.from(X.shape)]});
+  };
+  caseQrLs('lstsq_qr_40x40', 91, [40, 40], 92, [40, 3]);
+  caseQrLs('lstsq_qr_70x30', 93, [70, 30], 94, [70, 5]);
+  caseQrLs('lstsq_qr_full_50x20', 95, [50, 20], 96, [50, 2], true);
+  caseQrLs('lstsq_qr_bcast', 97, [3, 24, 10], 98, [24, 4]);
+  caseQrLs('lstsq_qr_130x100', 99, [130, 100], 100, [130, 70]);
+  caseQrLs('lstsq_qr_1x1', 101, [1, 1], 102, [1, 2]);
+  caseSvdLs('lstsq_svd_40x40', 'svd_lstsq', 103, [40, 40], 104, [40, 3]);
+  caseSvdLs('lstsq_svd_60x25', 'svd_lstsq', 105, [60, 25], 106, [60, 4]);
+  caseSvdLs('lstsq_svd_25x60', 'svd_lstsq', 107, [25, 60], 108, [25, 4]);
+  caseSvdLs('lstsq_svd_rankdef', 'svd_lstsq', 109, [30, 12], 110, [30, 2], true);
+  caseSvdLs('lstsq_svd_bcast', 'svd_lstsq', 111, [2, 20, 8], 112, [20, 3]);
+  caseSvdLs('lstsq_svd_100x70', 'svd_lstsq', 113, [100, 70], 114, [100, 66]);
+  caseSvdLs('solve_svd_32', 'svd_solve', 115, [32, 32], 116, [32, 5]);
+  caseSvdLs('solve_svd_rankdef', 'svd_solve', 117, [16, 16], 118, [16, 2], true);   // the reference returns (its rank loop never runs)
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

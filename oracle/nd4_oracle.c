@@ -229,6 +229,48 @@ void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_
   }
 }
 
+/* src/la/qr.js:186-273 qr_lstsq core (:232-241): x[0:L] = Q^T y accumulated k-innermost, then _triu_solve(L,I,J) */
+void nd4o_qr_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* Q, int64_t sQ, const double* R, int64_t sR,
+                   const double* Y, int64_t sY, double* X) {
+  const int64_t L = M < I ? M : I;
+  for (int64_t b = 0; b < batch; b++) {
+    const double* q = Q + b * sQ; const double* r = R + b * sR; const double* y = Y + b * sY; double* x = X + b * I * J;
+    for (int64_t e = 0; e < I * J; e++) x[e] = 0.0;
+    for (int64_t i = 0; i < L; i++)
+      for (int64_t j = 0; j < J; j++)
+        for (int64_t k = 0; k < N; k++) x[i * J + j] += q[k * M + i] * y[k * J + j];
+    triu_solve1(L, I, J, r, x);
+  }
+}
+
+/* src/la/svd.js:100-228 svd_lstsq core (:165-201). Returns -1 on a non-finite singular value (:171-172). */
+int nd4o_svd_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* U, int64_t sU, const double* SV, int64_t sSv,
+                   const double* V, int64_t sV, const double* Y, int64_t sY, double* X, double* tmp /* M*J */) {
+  const double EPS = 1.4901161193847656e-08;                /* Math.sqrt(2^-52), exact */
+  for (int64_t b = 0; b < batch; b++) {
+    const double* u = U + b * sU; const double* sv = SV + b * sSv; const double* v = V + b * sV; const double* y = Y + b * sY;
+    double* x = X + b * I * J;
+    const double T = EPS * fabs(sv[0]);
+    int64_t rank = M;
+    for (int64_t r = 0; r < M; r++) {
+      const double sv_r = fabs(sv[r]);
+      if (!isfinite(sv_r)) return -1;
+      if (sv_r <= T) { rank = r; break; }
+    }
+    for (int64_t e = 0; e < M * J; e++) tmp[e] = 0.0;
+    for (int64_t e = 0; e < I * J; e++) x[e] = 0.0;
+    for (int64_t k = 0; k < N; k++)
+      for (int64_t i = 0; i < rank; i++)
+        for (int64_t j = 0; j < J; j++) tmp[J * i + j] += u[M * k + i] * y[J * k + j];
+    for (int64_t i = 0; i < rank; i++)
+      for (int64_t j = 0; j < J; j++) tmp[J * i + j] /= sv[i];
+    for (int64_t k = 0; k < rank; k++)
+      for (int64_t i = 0; i < I; i++)
+        for (int64_t j = 0; j < J; j++) x[J * i + j] += v[I * k + i] * tmp[J * k + j];
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ two-sided Jacobi SVD */
 /* _svd_jac_utils.js:72-114 */
 static void svd_jac_angles(double S_pp, double S_pq, double S_qp, double S_qq,

@@ -52,6 +52,14 @@ void nd4o_triu_solve(int64_t batch, int64_t M, int64_t O, const double* U, int64
 void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU, const int32_t* P, int64_t strideP,
                    const double* Y, int64_t strideY, double* X);
 
+/* src/la/qr.js:186-273 qr_lstsq core: Q [N,M], R [M,I], Y [N,J] -> X [I,J] (strides in doubles, 0 = broadcast) */
+void nd4o_qr_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* Q, int64_t strideQ, const double* R, int64_t strideR,
+                   const double* Y, int64_t strideY, double* X);
+/* src/la/svd.js:100-228 svd_lstsq core: U [N,M], sv [M], V [M,I], Y [N,J] -> X [I,J]; tmp = M*J doubles.
+ * Returns -1 if a singular value is NaN/Inf (the reference throws). */
+int nd4o_svd_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* U, int64_t strideU, const double* SV, int64_t strideSv,
+                   const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X, double* tmp);
+
 /* src/la/svd_jac_2sided.js:30-144 (square input only; the rectangular pre-reduction :42-52 is
  * host-side composition) + _svd_jac_utils.js:72-114 (angles), :123-188 (post-processing).
  * U[batch,N,N], sv[batch,N], V[batch,N,N] (rows of V = right singular vectors). Returns sweeps. */

@@ -37,6 +37,11 @@ if (mode === 'cpu') {
   assert.throws(() => la.lu_decomp([[1, 2, 3], [4, 5, 6]]), /quadratic/);
   assert.throws(() => la.triu_solve([[1, 2, 3], [4, 5, 6]], [[1], [2]]), /must be quadratic/);
   assert.throws(() => la.lu_solve([[1, 0], [0, 1]], new la.NDArray(Int32Array.of(2), Int32Array.of(0, 1)), [[1], [2], [3]]), /LU and y don't match/);
+  assert.throws(() => la.qr_lstsq(fill(1, [4, 3]), fill(2, [3, 3]), fill(3, [5, 1])), /Q and y don't match/);
+  assert.throws(() => la.qr_lstsq(fill(1, [3, 3]), fill(2, [3, 5]), fill(3, [3, 1])), /Under-determined/);
+  assert.throws(() => la.svd_lstsq(fill(1, [4, 3]), fill(2, [2]), fill(3, [3, 3]), fill(4, [4, 1])), /U and sv don't match/);
+  assert.throws(() => la.svd_lstsq(fill(1, [2, 2]), new la.NDArray(Int32Array.of(2), Float64Array.of(1, NaN)), fill(3, [2, 2]), fill(4, [2, 1])), /NaN or Infinity/);
+  assert.throws(() => la.svd_solve(fill(1, [4, 3]), fill(2, [3]), fill(3, [3, 3]), fill(4, [4, 1])), /System not square/);
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
   assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
   assert.ok(/gfx950/.test(la.version()));
@@ -83,6 +88,11 @@ if (mode === 'gpu') {
     for (let i = 0; i < M; i++) for (let j = 0; j < M; j++) { const k = i * M + j;
       if (i === j) T.data[k] += T.data[k] >= 0 ? 2 : -2; else if (j > i) T.data[k] = 0; else T.data[k] *= 0.25; }
     const X = la.tril_solve(T, fill(m.seedY, m.shapeY)), ref = npy('solve_tril_bcast', 'X');
+    assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-12); }
+  { const m = man.lstsq_qr_bcast, X = la.qr_lstsq(la.qr_decomp(fill(m.seedA, m.shapeA)), fill(m.seedY, m.shapeY)), ref = npy('lstsq_qr_bcast', 'X');
+    assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-11); }
+  { const m = man.lstsq_svd_rankdef, n = k => { const a = npy('lstsq_svd_rankdef', k); return new la.NDArray(Int32Array.from(a.shape), a.data); };
+    const X = la.svd_lstsq(n('U'), n('sv'), n('V'), fill(m.seedY, m.shapeY)), ref = npy('lstsq_svd_rankdef', 'X');
     assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-12); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');

@@ -78,3 +78,108 @@ def test_lu_solve_2048(la):
     y = rng.matrix(3300, N, 8)
     x = la.lu_solve(la.lu_decomp(a), y)
     assert np.abs(a @ x - y).max() <= 1e-9
+
+
+# ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ----
+@pytest.mark.parametrize("name", golden_cases(op="qr_lstsq"))
+def test_qr_lstsq_golden(la, golden, name):
+    """Same (Q,R) as the reference (the oracle's Givens QR is bit-identical) -> only the solve differs."""
+    g = golden(name)
+    a = rng.matrix(g.seedA, *g.shapeA)
+    y = rng.matrix(g.seedY, *g.shapeY)
+    q, r = (oracle.qr_decomp_full if g.full else oracle.qr_decomp)(a)
+    x = la.qr_lstsq(q, r, y)
+    ref = g["X"]
+    assert x.shape == ref.shape
+    assert relerr(x, ref) <= 1e-14 * max(np.linalg.cond(a).max(), 10)
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases(op="qr_lstsq") if "full" not in c])
+def test_qr_lstsq_chain_on_gpu(la, golden, name):
+    """qr_decomp -> qr_lstsq both on the GPU (Householder Q,R differ from Givens by rounding only)."""
+    g = golden(name)
+    a = rng.matrix(g.seedA, *g.shapeA)
+    x = la.qr_lstsq(la.qr_decomp(a), rng.matrix(g.seedY, *g.shapeY))
+    assert relerr(x, g["X"]) <= 1e-13 * max(np.linalg.cond(a).max(), 10)
+
+
+@pytest.mark.parametrize("name", golden_cases(op="svd_lstsq") + golden_cases(op="svd_solve"))
+def test_svd_lstsq_golden(la, golden, name):
+    g = golden(name)
+    y = rng.matrix(g.seedY, *g.shapeY)
+    fn = la.svd_solve if g.op == "svd_solve" else la.svd_lstsq
+    x = fn(g["U"], g["sv"], g["V"], y)
+    ref = g["X"]
+    assert x.shape == ref.shape
+    sv = g["sv"]
+    rank = la.svd_rank(sv)
+    cond = (sv[..., 0] / np.take_along_axis(sv, np.maximum(rank - 1, 0)[..., None], -1)[..., 0]).max()
+    assert relerr(x, ref) <= 1e-14 * max(cond, 10)
+    if g.rankDef:
+        assert np.all(rank == sv.shape[-1] - 1)
+
+
+@pytest.mark.parametrize("N,I,J", [(1, 1, 1), (40, 40, 1), (97, 33, 5), (300, 200, 130), (1024, 512, 64), (2048, 2048, 8)])
+def test_qr_lstsq_vs_oracle_and_normal_equations(la, N, I, J):
+    a = rng.matrix(3400 + N, N, I)
+    y = rng.matrix(3500 + J, N, J)
+    q, r = la.qr_decomp(a)
+    x = la.qr_lstsq(q, r, y)
+    cond = np.linalg.cond(a)
+    if N <= 300:
+        assert relerr(x, oracle.qr_lstsq(q, r, y)) <= 1e-14 * max(cond, 10)
+    # least-squares optimality: A^T (A x - y) = 0
+    assert np.abs(a.T @ (a @ x - y)).max() <= 1e-11 * max(cond, 10) * np.abs(y).max() * np.sqrt(N)
+
+
+@pytest.mark.parametrize("N,I,J", [(64, 64, 3), (200, 120, 7), (120, 200, 7), (512, 512, 33)])
+def test_svd_lstsq_chain_on_gpu(la, N, I, J):
+    """svd_decomp -> svd_lstsq both on the GPU: minimum-norm least-squares solution == pinv(A) y."""
+    a = rng.matrix(3600 + N, N, I)
+    y = rng.matrix(3700 + J, N, J)
+    x = la.svd_lstsq(la.svd_decomp(a), y)
+    ref = np.linalg.pinv(a) @ y
+    assert relerr(x, ref) <= 1e-13 * max(np.linalg.cond(a), 10)
+
+
+def test_svd_lstsq_rank_cut_on_gpu(la):
+    """Exactly rank-deficient system: components below sqrt(eps)*sv_0 are dropped (svd.js:165-177), not divided by."""
+    b = rng.matrix(3800, 96, 40)
+    a = b @ rng.matrix(3801, 40, 64)                       # 96 x 64, rank 40
+    y = rng.matrix(3802, 96, 3)
+    u, sv, v = la.svd_decomp(a)
+    assert int(la.svd_rank(sv)) == 40
+    x = la.svd_lstsq(u, sv, v, y)
+    assert relerr(x, oracle.svd_lstsq(u, sv, v, y)) <= 1e-13
+    assert relerr(x, np.linalg.pinv(a, rcond=1e-8) @ y) <= 1e-9
+
+
+def test_lstsq_device_resident(la):
+    import torch
+    from nd4js_amd import dev
+    a = rng.matrix(3900, 3, 80, 48)
+    y = rng.matrix(3901, 3, 80, 6)
+    ad, yd = torch.from_numpy(a).cuda(), torch.from_numpy(y).cuda()
+    q, r = dev.qr_decomp(ad)
+    x1 = dev.qr_lstsq(q, r, yd).cpu().numpy()
+    u, sv, v = dev.svd_decomp(ad)
+    x2 = dev.svd_lstsq(u, sv, v, yd).cpu().numpy()
+    ref = np.linalg.pinv(a) @ y
+    assert relerr(x1, ref) <= 1e-12 and relerr(x2, ref) <= 1e-12
+
+
+def test_lstsq_errors_match_reference_text(la):
+    with pytest.raises(ValueError, match="Q and y don't match"):
+        la.qr_lstsq(np.ones((4, 3)), np.ones((3, 3)), np.ones((5, 1)))
+    with pytest.raises(ValueError, match="Q and R don't match"):
+        la.qr_lstsq(np.ones((4, 3)), np.ones((2, 3)), np.ones((4, 1)))
+    with pytest.raises(ValueError, match="Under-determined"):
+        la.qr_lstsq(np.ones((3, 3)), np.ones((3, 5)), np.ones((3, 1)))
+    with pytest.raises(ValueError, match="not broadcast-compatible"):
+        la.qr_lstsq(np.ones((2, 4, 3)), np.ones((3, 3, 3)), np.ones((4, 1)))
+    with pytest.raises(ValueError, match="U and sv don't match"):
+        la.svd_lstsq(np.ones((4, 3)), np.ones(2), np.ones((3, 3)), np.ones((4, 1)))
+    with pytest.raises(ValueError, match="NaN or Infinity"):
+        la.svd_lstsq(np.eye(2), np.array([1.0, np.inf]), np.eye(2), np.ones((2, 1)))
+    with pytest.raises(ValueError, match="System not square"):
+        la.svd_solve(np.ones((4, 3)), np.ones(3), np.ones((3, 3)), np.ones((4, 1)))

@@ -133,3 +133,29 @@ def test_tri_solve_bit_exact(golden, name):
     t = triangle(g.seedT, g.shapeT, upper)
     x = (oracle.triu_solve if upper else oracle.tril_solve)(t, rng.matrix(g.seedY, *g.shapeY))
     assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+# ---- least-squares consumers (qr.js:186-273, svd.js:66-228) ----
+@pytest.mark.parametrize("name", golden_cases(op="qr_lstsq"))
+def test_qr_lstsq_bit_exact(golden, name):
+    g = golden(name)
+    a = rng.matrix(g.seedA, *g.shapeA)
+    q, r = (oracle.qr_decomp_full if g.full else oracle.qr_decomp)(a)
+    x = oracle.qr_lstsq(q, r, rng.matrix(g.seedY, *g.shapeY))
+    assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+@pytest.mark.parametrize("name", golden_cases(op="svd_lstsq") + golden_cases(op="svd_solve"))
+def test_svd_lstsq_bit_exact(golden, name):
+    g = golden(name)
+    x = oracle.svd_lstsq(g["U"], g["sv"], g["V"], rng.matrix(g.seedY, *g.shapeY))
+    assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+def test_lstsq_errors():
+    with pytest.raises(ValueError, match="Q and y don't match"):
+        oracle.qr_lstsq(np.ones((4, 3)), np.ones((3, 3)), np.ones((5, 1)))
+    with pytest.raises(ValueError, match="Under-determined"):
+        oracle.qr_lstsq(np.ones((3, 3)), np.ones((3, 5)), np.ones((3, 1)))
+    with pytest.raises(ValueError, match="NaN or Infinity"):
+        oracle.svd_lstsq(np.eye(2), np.array([1.0, np.nan]), np.eye(2), np.ones((2, 1)))
