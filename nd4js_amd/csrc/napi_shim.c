@@ -3,10 +3,14 @@
  *
  * Plain C, built without node-gyp:  gcc -shared -fPIC -I/usr/include/node napi_shim.c -ldl
  * libnd4hip.so is dlopen'ed from the directory above this addon, so the addon itself has no HIP
- * link-time dependency. Every export takes TypedArrays (host memory, exactly what NDArray.data is in
- * the reference, src/nd_array.js:135-147) and calls the HOST-pointer entry points, which do
- * H2D -> kernels -> D2H synchronously: same blocking semantics as the reference's JS functions.
- * Errors become JS exceptions carrying nd4hip_last_error(). There is no CPU fallback here.
+ * link-time dependency. Every array operand of a compute export is EITHER
+ *   - a TypedArray (host memory, exactly what NDArray.data is in the reference, src/nd_array.js:135-147):
+ *     the HOST-pointer entry points run H2D -> kernels -> D2H synchronously, the blocking semantics of
+ *     the reference's JS functions; OR
+ *   - a device view {b: <buffer from dev_alloc>, o: <element offset>} (device-resident
+ *     NDArray): the `_dev` entry points run on the handle's stream and nothing crosses PCIe.
+ * All operands of one call must live on the same side. Errors become JS exceptions carrying
+ * nd4hip_last_error(). There is no CPU fallback here.
  */
 #define _GNU_SOURCE
 #define NAPI_VERSION 6
@@ -21,20 +25,35 @@
 static void* g_lib = NULL;
 static nd4hip_handle* g_handle = NULL;
 
+typedef int (*gemm_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
+typedef int (*getrf_fn)(nd4hip_handle*, int64_t, int64_t, const double*, double*, int32_t*);
+typedef int (*geqrf_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*);
+typedef int (*gesvdj_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*, int*, double*);
+typedef int (*qrls_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t, double*);
+typedef int (*svdls_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t,
+                        const double*, int64_t, double*);
+typedef int (*getrs_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const int32_t*, int64_t, const double*, int64_t, double*);
+typedef int (*trsm_fn)(nd4hip_handle*, int, int, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
+
 static int  (*p_device_count)(void);
 static int  (*p_create)(nd4hip_handle**, int);
 static void (*p_destroy)(nd4hip_handle*);
 static const char* (*p_last_error)(void);
 static const char* (*p_version)(void);
-static int (*p_dgemm)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
-static int (*p_dgetrf)(nd4hip_handle*, int64_t, int64_t, const double*, double*, int32_t*);
-static int (*p_dgeqrf)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*);
-static int (*p_dgesvdj)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*, int*, double*);
-static int (*p_dqrls)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t, double*);
-static int (*p_dsvdls)(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, const double*, int64_t,
-                       const double*, int64_t, double*);
-static int (*p_dgetrs)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const int32_t*, int64_t, const double*, int64_t, double*);
-static int (*p_dtrsm)(nd4hip_handle*, int, int, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
+/* [0] = host-pointer entry point, [1] = its _dev twin */
+static gemm_fn p_dgemm[2];
+static getrf_fn p_dgetrf[2];
+static geqrf_fn p_dgeqrf[2];
+static gesvdj_fn p_dgesvdj[2];
+static qrls_fn p_dqrls[2];
+static svdls_fn p_dsvdls[2];
+static getrs_fn p_dgetrs[2];
+static trsm_fn p_dtrsm[2];
+static int (*p_malloc)(nd4hip_handle*, size_t, void**);
+static int (*p_free)(nd4hip_handle*, void*);
+static int (*p_h2d)(nd4hip_handle*, void*, const void*, size_t);
+static int (*p_d2h)(nd4hip_handle*, void*, const void*, size_t);
+static int (*p_sync)(nd4hip_handle*);
 
 static char g_load_error[512] = "";
 
@@ -64,14 +83,21 @@ static int load_library(void) {
   SYM(p_destroy, "nd4hip_destroy");
   SYM(p_last_error, "nd4hip_last_error");
   SYM(p_version, "nd4hip_version");
-  SYM(p_dgemm, "nd4hip_dgemm_batched");
-  SYM(p_dgetrf, "nd4hip_dgetrf_batched");
-  SYM(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
-  SYM(p_dgesvdj, "nd4hip_dgesvdj_batched");
-  SYM(p_dgetrs, "nd4hip_dgetrs_batched");
-  SYM(p_dqrls, "nd4hip_dqrls_batched");
-  SYM(p_dsvdls, "nd4hip_dsvdls_batched");
-  SYM(p_dtrsm, "nd4hip_dtrsm_batched");
+#define SYM2(var, name) SYM(var[0], name); SYM(var[1], name "_dev")
+  SYM2(p_dgemm, "nd4hip_dgemm_batched");
+  SYM2(p_dgetrf, "nd4hip_dgetrf_batched");
+  SYM2(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
+  SYM2(p_dgesvdj, "nd4hip_dgesvdj_batched");
+  SYM2(p_dgetrs, "nd4hip_dgetrs_batched");
+  SYM2(p_dqrls, "nd4hip_dqrls_batched");
+  SYM2(p_dsvdls, "nd4hip_dsvdls_batched");
+  SYM2(p_dtrsm, "nd4hip_dtrsm_batched");
+#undef SYM2
+  SYM(p_malloc, "nd4hip_malloc");
+  SYM(p_free, "nd4hip_free");
+  SYM(p_h2d, "nd4hip_memcpy_h2d");
+  SYM(p_d2h, "nd4hip_memcpy_d2h");
+  SYM(p_sync, "nd4hip_synchronize");
 #undef SYM
   return 0;
 }
@@ -107,6 +133,60 @@ static int get_ta(napi_env env, napi_value v, napi_typedarray_type want, void** 
   }
   return 0;
 }
+
+/* ---- device buffers: an external with a finalizer; JS passes views {b: buffer, o: element offset} ---- */
+#define DEVBUF_MAGIC 0x6e64346869706466ull
+typedef struct { uint64_t magic; void* p; size_t bytes; } devbuf;
+
+static void devbuf_release(devbuf* b) {
+  if (b->p && g_handle && p_free) p_free(g_handle, b->p);     /* after the env cleanup hook the handle (and its memory) is gone */
+  b->p = NULL;
+}
+static void devbuf_finalize(napi_env env, void* data, void* hint) {
+  (void)hint;
+  devbuf* b = (devbuf*)data;
+  if (b->p) { int64_t adj; napi_adjust_external_memory(env, -(int64_t)b->bytes, &adj); }
+  devbuf_release(b);
+  free(b);
+}
+static devbuf* get_devbuf(napi_env env, napi_value v) {
+  napi_valuetype t;
+  void* data = NULL;
+  if (napi_typeof(env, v, &t) != napi_ok || t != napi_external || napi_get_value_external(env, v, &data) != napi_ok ||
+      !data || ((devbuf*)data)->magic != DEVBUF_MAGIC) {
+    napi_throw_type_error(env, "ND4HIP", "expected a device buffer from dev_alloc()");
+    return NULL;
+  }
+  return (devbuf*)data;
+}
+
+/* one array operand: host TypedArray, or device view {b, o}; len = elements available from p */
+typedef struct { void* p; size_t len; int dev; } opnd;
+static int get_op(napi_env env, napi_value v, napi_typedarray_type want, opnd* out) {
+  bool is_ta = false;
+  napi_is_typedarray(env, v, &is_ta);
+  if (is_ta) { out->dev = 0; return get_ta(env, v, want, &out->p, &out->len); }
+  napi_valuetype t;
+  napi_value vb, vo;
+  if (napi_typeof(env, v, &t) != napi_ok || t != napi_object || napi_get_named_property(env, v, "b", &vb) != napi_ok ||
+      napi_get_named_property(env, v, "o", &vo) != napi_ok) {
+    napi_throw_type_error(env, "ND4HIP", "expected a TypedArray or a device view {b, o}");
+    return -1;
+  }
+  devbuf* b = get_devbuf(env, vb);
+  if (!b) return -1;
+  if (!b->p) { napi_throw_error(env, "ND4HIP", "device buffer was already freed"); return -1; }
+  int64_t off;
+  if (get_i64(env, vo, &off)) return -1;
+  const size_t esz = want == napi_float64_array ? 8 : 4, total = b->bytes / esz;
+  if (off < 0 || (size_t)off > total) { napi_throw_range_error(env, "ND4HIP", "device view offset out of range"); return -1; }
+  out->p = (char*)b->p + (size_t)off * esz;
+  out->len = total - (size_t)off;
+  out->dev = 1;
+  return 0;
+}
+#define SAME_SIDE(cond, name) do { if (!(cond)) { napi_throw_type_error(env, "ND4HIP", name ": operands must be all host TypedArrays or all device views"); return NULL; } } while (0)
+
 #define NEED(cond, msg) do { if (!(cond)) { napi_throw_range_error(env, "ND4HIP", msg); return NULL; } } while (0)
 
 static napi_value js_device_count(napi_env env, napi_callback_info info) {
@@ -124,68 +204,63 @@ static napi_value js_version(napi_env env, napi_callback_info info) {
   return r;
 }
 
+#define ARGS(n, name) size_t argc = (n); napi_value a[(n)]; napi_get_cb_info(env, info, &argc, a, NULL, NULL); \
+  NEED(argc == (n), name ": " #n " arguments expected")
+#define F64(i, o) get_op(env, a[i], napi_float64_array, &(o))
+#define I32(i, o) get_op(env, a[i], napi_int32_array, &(o))
+#define FAIL_IF(rc) do { if ((rc) != 0) THROW(env, p_last_error()); } while (0)
+
 /* dgemm_batched(batch, I, K, J, A, strideA, B, strideB, C) */
 static napi_value js_dgemm(napi_env env, napi_callback_info info) {
-  size_t argc = 9; napi_value a[9];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 9, "dgemm_batched: 9 arguments expected");
-  int64_t batch, I, K, J, sA, sB; void *A, *B, *C; size_t nA, nB, nC;
+  ARGS(9, "dgemm_batched");
+  int64_t batch, I, K, J, sA, sB; opnd A, B, C;
   if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &I) || get_i64(env, a[2], &K) || get_i64(env, a[3], &J) ||
-      get_ta(env, a[4], napi_float64_array, &A, &nA) || get_i64(env, a[5], &sA) ||
-      get_ta(env, a[6], napi_float64_array, &B, &nB) || get_i64(env, a[7], &sB) ||
-      get_ta(env, a[8], napi_float64_array, &C, &nC)) return NULL;
+      F64(4, A) || get_i64(env, a[5], &sA) || F64(6, B) || get_i64(env, a[7], &sB) || F64(8, C)) return NULL;
   NEED(batch >= 0 && I >= 0 && K >= 0 && J >= 0 && sA >= 0 && sB >= 0, "dgemm_batched: negative extent");
-  NEED(batch == 0 || ((size_t)((batch - 1) * sA + I * K) <= nA && (size_t)((batch - 1) * sB + K * J) <= nB && (size_t)(batch * I * J) <= nC),
+  NEED(batch == 0 || ((size_t)((batch - 1) * sA + I * K) <= A.len && (size_t)((batch - 1) * sB + K * J) <= B.len && (size_t)(batch * I * J) <= C.len),
        "dgemm_batched: buffer too small");
+  SAME_SIDE(A.dev == B.dev && B.dev == C.dev, "dgemm_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dgemm(g_handle, batch, I, K, J, (const double*)A, sA, (const double*)B, sB, (double*)C) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dgemm[A.dev](g_handle, batch, I, K, J, (const double*)A.p, sA, (const double*)B.p, sB, (double*)C.p));
   return NULL;
 }
 /* dgetrf_batched(batch, N, A, LU, P) */
 static napi_value js_dgetrf(napi_env env, napi_callback_info info) {
-  size_t argc = 5; napi_value a[5];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 5, "dgetrf_batched: 5 arguments expected");
-  int64_t batch, N; void *A, *LU, *P; size_t nA, nLU, nP;
-  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_ta(env, a[2], napi_float64_array, &A, &nA) ||
-      get_ta(env, a[3], napi_float64_array, &LU, &nLU) || get_ta(env, a[4], napi_int32_array, &P, &nP)) return NULL;
-  NEED(batch >= 0 && N >= 0 && (size_t)(batch * N * N) <= nA && (size_t)(batch * N * N) <= nLU && (size_t)(batch * N) <= nP,
+  ARGS(5, "dgetrf_batched");
+  int64_t batch, N; opnd A, LU, P;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || F64(2, A) || F64(3, LU) || I32(4, P)) return NULL;
+  NEED(batch >= 0 && N >= 0 && (size_t)(batch * N * N) <= A.len && (size_t)(batch * N * N) <= LU.len && (size_t)(batch * N) <= P.len,
        "dgetrf_batched: buffer too small");
+  SAME_SIDE(A.dev == LU.dev && LU.dev == P.dev, "dgetrf_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dgetrf(g_handle, batch, N, (const double*)A, (double*)LU, (int32_t*)P) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dgetrf[A.dev](g_handle, batch, N, (const double*)A.p, (double*)LU.p, (int32_t*)P.p));
   return NULL;
 }
 /* dgeqrf_q_batched(batch, M, N, A, Q, R) */
 static napi_value js_dgeqrf(napi_env env, napi_callback_info info) {
-  size_t argc = 6; napi_value a[6];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 6, "dgeqrf_q_batched: 6 arguments expected");
-  int64_t batch, M, N; void *A, *Q, *R; size_t nA, nQ, nR;
-  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) ||
-      get_ta(env, a[3], napi_float64_array, &A, &nA) || get_ta(env, a[4], napi_float64_array, &Q, &nQ) ||
-      get_ta(env, a[5], napi_float64_array, &R, &nR)) return NULL;
+  ARGS(6, "dgeqrf_q_batched");
+  int64_t batch, M, N; opnd A, Q, R;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) || F64(3, A) || F64(4, Q) || F64(5, R)) return NULL;
   int64_t L = M < N ? M : N;
-  NEED(batch >= 0 && M >= 0 && N >= 0 && (size_t)(batch * M * N) <= nA && (size_t)(batch * M * L) <= nQ && (size_t)(batch * L * N) <= nR,
+  NEED(batch >= 0 && M >= 0 && N >= 0 && (size_t)(batch * M * N) <= A.len && (size_t)(batch * M * L) <= Q.len && (size_t)(batch * L * N) <= R.len,
        "dgeqrf_q_batched: buffer too small");
+  SAME_SIDE(A.dev == Q.dev && Q.dev == R.dev, "dgeqrf_q_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dgeqrf(g_handle, batch, M, N, (const double*)A, (double*)Q, (double*)R) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dgeqrf[A.dev](g_handle, batch, M, N, (const double*)A.p, (double*)Q.p, (double*)R.p));
   return NULL;
 }
 /* dgesvdj_batched(batch, M, N, A, U, sv, V) -> {sweeps, offnorm} */
 static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
-  size_t argc = 7; napi_value a[7];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 7, "dgesvdj_batched: 7 arguments expected");
-  int64_t batch, M, N; void *A, *U, *S, *V; size_t nA, nU, nS, nV;
-  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) ||
-      get_ta(env, a[3], napi_float64_array, &A, &nA) || get_ta(env, a[4], napi_float64_array, &U, &nU) ||
-      get_ta(env, a[5], napi_float64_array, &S, &nS) || get_ta(env, a[6], napi_float64_array, &V, &nV)) return NULL;
+  ARGS(7, "dgesvdj_batched");
+  int64_t batch, M, N; opnd A, U, S, V;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) || F64(3, A) || F64(4, U) || F64(5, S) || F64(6, V)) return NULL;
   int64_t L = M < N ? M : N;
-  NEED(batch >= 0 && M >= 0 && N >= 0 && (size_t)(batch * M * N) <= nA && (size_t)(batch * M * L) <= nU &&
-       (size_t)(batch * L) <= nS && (size_t)(batch * L * N) <= nV, "dgesvdj_batched: buffer too small");
+  NEED(batch >= 0 && M >= 0 && N >= 0 && (size_t)(batch * M * N) <= A.len && (size_t)(batch * M * L) <= U.len &&
+       (size_t)(batch * L) <= S.len && (size_t)(batch * L * N) <= V.len, "dgesvdj_batched: buffer too small");
+  SAME_SIDE(A.dev == U.dev && U.dev == S.dev && S.dev == V.dev, "dgesvdj_batched");
   if (ensure_handle(env)) return NULL;
   int sweeps = 0; double off = 0.0;
-  if (p_dgesvdj(g_handle, batch, M, N, (const double*)A, (double*)U, (double*)S, (double*)V, &sweeps, &off) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dgesvdj[A.dev](g_handle, batch, M, N, (const double*)A.p, (double*)U.p, (double*)S.p, (double*)V.p, &sweeps, &off));
   napi_value r, v;
   napi_create_object(env, &r);
   napi_create_int32(env, sweeps, &v); napi_set_named_property(env, r, "sweeps", v);
@@ -195,77 +270,127 @@ static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
 
 /* dgetrs_batched(batch, N, J, LU, strideLU, P, strideP, Y, strideY, X)   (lu_solve, lu.js:84-177) */
 static napi_value js_dgetrs(napi_env env, napi_callback_info info) {
-  size_t argc = 10; napi_value a[10];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 10, "dgetrs_batched: 10 arguments expected");
-  int64_t batch, N, J, sLU, sP, sY; void *LU, *P, *Y, *X; size_t nLU, nP, nY, nX;
-  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &J) ||
-      get_ta(env, a[3], napi_float64_array, &LU, &nLU) || get_i64(env, a[4], &sLU) ||
-      get_ta(env, a[5], napi_int32_array, &P, &nP) || get_i64(env, a[6], &sP) ||
-      get_ta(env, a[7], napi_float64_array, &Y, &nY) || get_i64(env, a[8], &sY) ||
-      get_ta(env, a[9], napi_float64_array, &X, &nX)) return NULL;
+  ARGS(10, "dgetrs_batched");
+  int64_t batch, N, J, sLU, sP, sY; opnd LU, P, Y, X;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &J) || F64(3, LU) || get_i64(env, a[4], &sLU) ||
+      I32(5, P) || get_i64(env, a[6], &sP) || F64(7, Y) || get_i64(env, a[8], &sY) || F64(9, X)) return NULL;
   NEED(batch >= 0 && N >= 0 && J >= 0 && sLU >= 0 && sP >= 0 && sY >= 0, "dgetrs_batched: negative extent");
-  NEED(batch == 0 || ((size_t)((batch - 1) * sLU + N * N) <= nLU && (size_t)((batch - 1) * sP + N) <= nP &&
-                      (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * N * J) <= nX), "dgetrs_batched: buffer too small");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sLU + N * N) <= LU.len && (size_t)((batch - 1) * sP + N) <= P.len &&
+                      (size_t)((batch - 1) * sY + N * J) <= Y.len && (size_t)(batch * N * J) <= X.len), "dgetrs_batched: buffer too small");
+  SAME_SIDE(LU.dev == P.dev && P.dev == Y.dev && Y.dev == X.dev, "dgetrs_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dgetrs(g_handle, batch, N, J, (const double*)LU, sLU, (const int32_t*)P, sP, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dgetrs[X.dev](g_handle, batch, N, J, (const double*)LU.p, sLU, (const int32_t*)P.p, sP, (const double*)Y.p, sY, (double*)X.p));
   return NULL;
 }
 /* dtrsm_batched(upper, unit_diag, batch, M, J, T, strideT, Y, strideY, X)   (tril_solve / triu_solve, tri.js:155-290) */
 static napi_value js_dtrsm(napi_env env, napi_callback_info info) {
-  size_t argc = 10; napi_value a[10];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 10, "dtrsm_batched: 10 arguments expected");
-  int64_t upper, unit, batch, M, J, sT, sY; void *T, *Y, *X; size_t nT, nY, nX;
+  ARGS(10, "dtrsm_batched");
+  int64_t upper, unit, batch, M, J, sT, sY; opnd T, Y, X;
   if (get_i64(env, a[0], &upper) || get_i64(env, a[1], &unit) || get_i64(env, a[2], &batch) || get_i64(env, a[3], &M) || get_i64(env, a[4], &J) ||
-      get_ta(env, a[5], napi_float64_array, &T, &nT) || get_i64(env, a[6], &sT) ||
-      get_ta(env, a[7], napi_float64_array, &Y, &nY) || get_i64(env, a[8], &sY) ||
-      get_ta(env, a[9], napi_float64_array, &X, &nX)) return NULL;
+      F64(5, T) || get_i64(env, a[6], &sT) || F64(7, Y) || get_i64(env, a[8], &sY) || F64(9, X)) return NULL;
   NEED(batch >= 0 && M >= 0 && J >= 0 && sT >= 0 && sY >= 0, "dtrsm_batched: negative extent");
-  NEED(batch == 0 || ((size_t)((batch - 1) * sT + M * M) <= nT && (size_t)((batch - 1) * sY + M * J) <= nY && (size_t)(batch * M * J) <= nX),
+  NEED(batch == 0 || ((size_t)((batch - 1) * sT + M * M) <= T.len && (size_t)((batch - 1) * sY + M * J) <= Y.len && (size_t)(batch * M * J) <= X.len),
        "dtrsm_batched: buffer too small");
+  SAME_SIDE(T.dev == Y.dev && Y.dev == X.dev, "dtrsm_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dtrsm(g_handle, (int)upper, (int)unit, batch, M, J, (const double*)T, sT, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dtrsm[X.dev](g_handle, (int)upper, (int)unit, batch, M, J, (const double*)T.p, sT, (const double*)Y.p, sY, (double*)X.p));
   return NULL;
 }
-
 /* dqrls_batched(batch, N, M, I, J, Q, strideQ, R, strideR, Y, strideY, X)   (qr_lstsq, qr.js:186-273) */
 static napi_value js_dqrls(napi_env env, napi_callback_info info) {
-  size_t argc = 12; napi_value a[12];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 12, "dqrls_batched: 12 arguments expected");
-  int64_t batch, N, M, I, J, sQ, sR, sY; void *Q, *R, *Y, *X; size_t nQ, nR, nY, nX;
+  ARGS(12, "dqrls_batched");
+  int64_t batch, N, M, I, J, sQ, sR, sY; opnd Q, R, Y, X;
   if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &M) || get_i64(env, a[3], &I) || get_i64(env, a[4], &J) ||
-      get_ta(env, a[5], napi_float64_array, &Q, &nQ) || get_i64(env, a[6], &sQ) ||
-      get_ta(env, a[7], napi_float64_array, &R, &nR) || get_i64(env, a[8], &sR) ||
-      get_ta(env, a[9], napi_float64_array, &Y, &nY) || get_i64(env, a[10], &sY) ||
-      get_ta(env, a[11], napi_float64_array, &X, &nX)) return NULL;
+      F64(5, Q) || get_i64(env, a[6], &sQ) || F64(7, R) || get_i64(env, a[8], &sR) || F64(9, Y) || get_i64(env, a[10], &sY) || F64(11, X)) return NULL;
   NEED(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0 && sQ >= 0 && sR >= 0 && sY >= 0, "dqrls_batched: negative extent");
-  NEED(batch == 0 || ((size_t)((batch - 1) * sQ + N * M) <= nQ && (size_t)((batch - 1) * sR + M * I) <= nR &&
-                      (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * I * J) <= nX), "dqrls_batched: buffer too small");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sQ + N * M) <= Q.len && (size_t)((batch - 1) * sR + M * I) <= R.len &&
+                      (size_t)((batch - 1) * sY + N * J) <= Y.len && (size_t)(batch * I * J) <= X.len), "dqrls_batched: buffer too small");
+  SAME_SIDE(Q.dev == R.dev && R.dev == Y.dev && Y.dev == X.dev, "dqrls_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dqrls(g_handle, batch, N, M, I, J, (const double*)Q, sQ, (const double*)R, sR, (const double*)Y, sY, (double*)X) != 0) THROW(env, p_last_error());
+  FAIL_IF(p_dqrls[X.dev](g_handle, batch, N, M, I, J, (const double*)Q.p, sQ, (const double*)R.p, sR, (const double*)Y.p, sY, (double*)X.p));
   return NULL;
 }
 /* dsvdls_batched(batch, N, M, I, J, U, strideU, sv, strideSv, V, strideV, Y, strideY, X)   (svd_lstsq, svd.js:100-228) */
 static napi_value js_dsvdls(napi_env env, napi_callback_info info) {
-  size_t argc = 14; napi_value a[14];
-  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
-  NEED(argc == 14, "dsvdls_batched: 14 arguments expected");
-  int64_t batch, N, M, I, J, sU, sS, sV, sY; void *U, *S, *V, *Y, *X; size_t nU, nS, nV, nY, nX;
+  ARGS(14, "dsvdls_batched");
+  int64_t batch, N, M, I, J, sU, sS, sV, sY; opnd U, S, V, Y, X;
   if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &M) || get_i64(env, a[3], &I) || get_i64(env, a[4], &J) ||
-      get_ta(env, a[5], napi_float64_array, &U, &nU) || get_i64(env, a[6], &sU) ||
-      get_ta(env, a[7], napi_float64_array, &S, &nS) || get_i64(env, a[8], &sS) ||
-      get_ta(env, a[9], napi_float64_array, &V, &nV) || get_i64(env, a[10], &sV) ||
-      get_ta(env, a[11], napi_float64_array, &Y, &nY) || get_i64(env, a[12], &sY) ||
-      get_ta(env, a[13], napi_float64_array, &X, &nX)) return NULL;
+      F64(5, U) || get_i64(env, a[6], &sU) || F64(7, S) || get_i64(env, a[8], &sS) || F64(9, V) || get_i64(env, a[10], &sV) ||
+      F64(11, Y) || get_i64(env, a[12], &sY) || F64(13, X)) return NULL;
   NEED(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0 && sU >= 0 && sS >= 0 && sV >= 0 && sY >= 0, "dsvdls_batched: negative extent");
-  NEED(batch == 0 || ((size_t)((batch - 1) * sU + N * M) <= nU && (size_t)((batch - 1) * sS + M) <= nS &&
-                      (size_t)((batch - 1) * sV + M * I) <= nV && (size_t)((batch - 1) * sY + N * J) <= nY && (size_t)(batch * I * J) <= nX),
+  NEED(batch == 0 || ((size_t)((batch - 1) * sU + N * M) <= U.len && (size_t)((batch - 1) * sS + M) <= S.len &&
+                      (size_t)((batch - 1) * sV + M * I) <= V.len && (size_t)((batch - 1) * sY + N * J) <= Y.len && (size_t)(batch * I * J) <= X.len),
        "dsvdls_batched: buffer too small");
+  SAME_SIDE(U.dev == S.dev && S.dev == V.dev && V.dev == Y.dev && Y.dev == X.dev, "dsvdls_batched");
   if (ensure_handle(env)) return NULL;
-  if (p_dsvdls(g_handle, batch, N, M, I, J, (const double*)U, sU, (const double*)S, sS, (const double*)V, sV, (const double*)Y, sY, (double*)X) != 0)
-    THROW(env, p_last_error());
+  FAIL_IF(p_dsvdls[X.dev](g_handle, batch, N, M, I, J, (const double*)U.p, sU, (const double*)S.p, sS, (const double*)V.p, sV,
+                          (const double*)Y.p, sY, (double*)X.p));
+  return NULL;
+}
+
+/* ---- device memory ---- */
+/* dev_alloc(bytes) -> buffer */
+static napi_value js_dev_alloc(napi_env env, napi_callback_info info) {
+  ARGS(1, "dev_alloc");
+  int64_t bytes;
+  if (get_i64(env, a[0], &bytes)) return NULL;
+  NEED(bytes >= 0, "dev_alloc: negative size");
+  if (ensure_handle(env)) return NULL;
+  devbuf* b = (devbuf*)calloc(1, sizeof(devbuf));
+  if (!b) THROW(env, "dev_alloc: out of host memory");
+  b->magic = DEVBUF_MAGIC; b->bytes = (size_t)bytes;
+  if (p_malloc(g_handle, b->bytes, &b->p) != 0) { free(b); THROW(env, p_last_error()); }
+  napi_value r;
+  if (napi_create_external(env, b, devbuf_finalize, NULL, &r) != napi_ok) { devbuf_release(b); free(b); THROW(env, "dev_alloc: napi_create_external failed"); }
+  int64_t adj; napi_adjust_external_memory(env, (int64_t)b->bytes, &adj);     /* let the GC see the device bytes it keeps alive */
+  return r;
+}
+/* dev_free(buffer): idempotent; the finalizer covers buffers that are simply dropped */
+static napi_value js_dev_free(napi_env env, napi_callback_info info) {
+  ARGS(1, "dev_free");
+  devbuf* b = get_devbuf(env, a[0]);
+  if (!b) return NULL;
+  if (b->p) { int64_t adj; napi_adjust_external_memory(env, -(int64_t)b->bytes, &adj); devbuf_release(b); b->bytes = 0; }
+  return NULL;
+}
+static int get_any_ta(napi_env env, napi_value v, void** data, size_t* bytes) {
+  bool is_ta = false;
+  napi_is_typedarray(env, v, &is_ta);
+  napi_typedarray_type type; napi_value buf; size_t off, len;
+  if (!is_ta || napi_get_typedarray_info(env, v, &type, &len, data, &buf, &off) != napi_ok ||
+      (type != napi_float64_array && type != napi_int32_array)) {
+    napi_throw_type_error(env, "ND4HIP", "expected a Float64Array or an Int32Array");
+    return -1;
+  }
+  *bytes = len * (type == napi_float64_array ? 8 : 4);
+  return 0;
+}
+/* dev_upload(buffer, byteOffset, typedArray): blocking H2D */
+static napi_value js_dev_upload(napi_env env, napi_callback_info info) {
+  ARGS(3, "dev_upload");
+  devbuf* b = get_devbuf(env, a[0]);
+  int64_t off; void* src; size_t bytes;
+  if (!b || get_i64(env, a[1], &off) || get_any_ta(env, a[2], &src, &bytes)) return NULL;
+  NEED(b->p && off >= 0 && (size_t)off + bytes <= b->bytes, "dev_upload: out of range (or freed buffer)");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_h2d(g_handle, (char*)b->p + off, src, bytes));
+  return NULL;
+}
+/* dev_download(typedArray, buffer, byteOffset): blocking D2H after everything queued on the handle's stream */
+static napi_value js_dev_download(napi_env env, napi_callback_info info) {
+  ARGS(3, "dev_download");
+  devbuf* b = get_devbuf(env, a[1]);
+  int64_t off; void* dst; size_t bytes;
+  if (!b || get_i64(env, a[2], &off) || get_any_ta(env, a[0], &dst, &bytes)) return NULL;
+  NEED(b->p && off >= 0 && (size_t)off + bytes <= b->bytes, "dev_download: out of range (or freed buffer)");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_d2h(g_handle, dst, (const char*)b->p + off, bytes));
+  return NULL;
+}
+static napi_value js_synchronize(napi_env env, napi_callback_info info) {
+  (void)info;
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_sync(g_handle));
   return NULL;
 }
 
@@ -286,6 +411,11 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dqrls_batched", NULL, js_dqrls, NULL, NULL, NULL, napi_default, NULL},
     {"dsvdls_batched", NULL, js_dsvdls, NULL, NULL, NULL, napi_default, NULL},
     {"dtrsm_batched", NULL, js_dtrsm, NULL, NULL, NULL, napi_default, NULL},
+    {"dev_alloc", NULL, js_dev_alloc, NULL, NULL, NULL, napi_default, NULL},
+    {"dev_free", NULL, js_dev_free, NULL, NULL, NULL, napi_default, NULL},
+    {"dev_upload", NULL, js_dev_upload, NULL, NULL, NULL, napi_default, NULL},
+    {"dev_download", NULL, js_dev_download, NULL, NULL, NULL, napi_default, NULL},
+    {"synchronize", NULL, js_synchronize, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   napi_add_env_cleanup_hook(env, cleanup, NULL);

@@ -61,15 +61,52 @@ function fromNested(a) {           // nested JS arrays -> NDArray(float64)  (asa
   })(a, 0);
   return new NDArray(Int32Array.from(shape.length ? shape : [1]), data);
 }
+/* ---- device-resident arrays (SURVEY.md §8f N3): `data` stays in HBM across calls, lazy D2H on `.data` ----
+ * An extension of the NDArray contract (nd_array.js:128-158), not part of the reference: any nd.la hot-path function
+ * that receives at least one DeviceNDArray runs the `_dev` entry points (nothing crosses PCIe except host operands
+ * uploaded on the way in) and returns DeviceNDArrays. Results are immutable, so the host copy is cached. */
+class DevBuf {
+  constructor(length, Ctor) {
+    this.length = length; this.Ctor = Ctor;
+    this.ext = native().dev_alloc(length * Ctor.BYTES_PER_ELEMENT);
+  }
+  static from(typed) { const b = new DevBuf(typed.length, typed.constructor); native().dev_upload(b.ext, 0, typed); return b; }
+  view(off) { if (!this.ext) throw new Error('nd4hip: device array was disposed.'); return {b: this.ext, o: off}; }
+  free() { if (this.ext) { native().dev_free(this.ext); this.ext = null; } }
+}
+class DeviceNDArray {
+  constructor(shape, buf) {
+    if (!(shape instanceof Int32Array)) throw new Error('Shape must be Int32Array.');
+    if (!(buf instanceof DevBuf) || buf.length !== shape.reduce((a, b) => a * b, 1)) throw new Error(`Shape [${shape}] does not match the device buffer.`);
+    this.shape = shape; this._buf = buf; this._host = null;
+  }
+  get ndim() { return this.shape.length; }
+  get dtype() { return this._buf.Ctor === Int32Array ? 'int32' : 'float64'; }
+  get onDevice() { return true; }
+  get data() {                                   // lazy D2H (blocks until everything queued before it has finished)
+    if (this._host === null) {
+      if (!this._buf.ext) throw new Error('nd4hip: device array was disposed.');
+      const h = new this._buf.Ctor(this._buf.length);
+      native().dev_download(h, this._buf.ext, 0);
+      this._host = h;
+    }
+    return this._host;
+  }
+  toHost(NDA) { return new (NDA || NDArray)(Int32Array.from(this.shape), this.data); }
+  dispose() { this._buf.free(); }                // optional: dropped arrays are freed by the GC finalizer
+}
+const isDev = a => a instanceof DeviceNDArray;
+
 function makeAsarray(NDA) {
   return function asarray(a) {
+    if (isDev(a)) return a;                                                       // never touches .data (no D2H)
     if (a && a.shape instanceof Int32Array && a.data !== undefined) return a;     // NDArray of either package
     if (Array.isArray(a)) { const r = fromNested(a); return NDA === NDArray ? r : new NDA(r.shape, r.data); }
     if (typeof a === 'number') return new NDA(Int32Array.of(1), Float64Array.of(a));
     throw new Error('asarray(): unsupported argument.');
   };
 }
-const dtypeOf = a => a.data instanceof Float64Array ? 'float64' : a.data instanceof Int32Array ? 'int32' :
+const dtypeOf = a => isDev(a) ? a.dtype : a.data instanceof Float64Array ? 'float64' : a.data instanceof Int32Array ? 'int32' :
   a.data instanceof Float32Array ? 'float32' : (a.dtype || 'object');
 const f64 = a => a.data instanceof Float64Array ? a.data : Float64Array.from(a.data);    // int32 -> float64 promotion
 const prod = (s, from, to) => { let p = 1; for (let i = from; i < to; i++) p *= s[i]; return p; };
@@ -144,6 +181,26 @@ function makeLa(NDA, fallback) {
   const asarray = makeAsarray(NDA);
   const gpuOk = a => { const d = dtypeOf(a); return d === 'float64' || d === 'int32'; };
   const la = {};
+  /* residency plumbing: one code path per function, host TypedArrays or device buffers */
+  const alloc = (dev, n, Ctor) => dev ? new DevBuf(n, Ctor || Float64Array) : new (Ctor || Float64Array)(n);
+  const view = (x, off) => x instanceof DevBuf ? x.view(off) : x.subarray(off);
+  const wrap = (dev, shape, x) => dev ? new DeviceNDArray(Int32Array.from(shape), x) : new NDA(Int32Array.from(shape), x);
+  const opF64 = (a, dev, temps) => {             // operand storage as float64 on the side the call runs on
+    if (!dev) return f64(a);
+    if (isDev(a) && a.dtype === 'float64') return a._buf;
+    const b = DevBuf.from(f64(a)); temps.push(b); return b;      // host operand (or device int32): upload a float64 copy
+  };
+  const opI32 = (a, dev, temps) => {
+    if (!dev) return a.data;
+    if (isDev(a)) return a._buf;
+    const b = DevBuf.from(a.data); temps.push(b); return b;
+  };
+  const release = temps => { for (const t of temps) t.free(); };
+  la.DeviceNDArray = DeviceNDArray;
+  la.to_device = a => { a = asarray(a); if (isDev(a)) return a; if (!gpuOk(a)) throw new Error('nd4hip.to_device: dtype ' + dtypeOf(a) + ' is not accelerated.');
+                        return new DeviceNDArray(Int32Array.from(a.shape), DevBuf.from(a.data)); };
+  la.to_host = a => isDev(a) ? a.toHost(NDA) : asarray(a);
+  la.synchronize = () => native().synchronize();
 
   la.matmul2 = function matmul2(a, b) {
     a = asarray(a); b = asarray(b);
@@ -165,10 +222,12 @@ function makeLa(NDA, fallback) {
         if (1 === shape[i]) shape[i] = arr.shape[j];
         else if (shape[i] != arr.shape[j] && arr.shape[j] != 1) throw new Error('Shapes are not broadcast-compatible.');
     const lead = Array.from(shape.subarray(0, ndim - 2));
-    const A = f64(a), B = f64(b), C = new Float64Array(shape.reduce((m, n) => m * n, 1));
+    const dev = isDev(a) || isDev(b), temps = [];
+    const A = opF64(a, dev, temps), B = opF64(b, dev, temps), C = alloc(dev, shape.reduce((m, n) => m * n, 1));
     for (const [cnt, offA, sA, offB, sB, offC] of bcastGroups(lead, a.shape.subarray(0, a.ndim - 2), b.shape.subarray(0, b.ndim - 2), I * K, K * J))
-      native().dgemm_batched(cnt, I, K, J, A.subarray(offA), sA, B.subarray(offB), sB, C.subarray(offC * I * J));
-    return new NDA(shape, C);
+      native().dgemm_batched(cnt, I, K, J, view(A, offA), sA, view(B, offB), sB, view(C, offC * I * J));
+    release(temps);
+    return wrap(dev, shape, C);
   };
 
   la.matmul = function matmul(...matrices) {            // chain ordering stays on the host (matmul.js:150-236)
@@ -217,9 +276,11 @@ function makeLa(NDA, fallback) {
     if (!gpuOk(A)) { if (fallback && fallback.qr_decomp) return fallback.qr_decomp(A); throw new Error('nd4hip.qr_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
     const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], L = Math.min(M, N), batch = prod(A.shape, 0, nd_ - 2);
     const Qs = Int32Array.from(A.shape), Rs = Int32Array.from(A.shape); Qs[nd_ - 1] = L; Rs[nd_ - 2] = L;
-    const Q = new Float64Array(batch * M * L), R = new Float64Array(batch * L * N);
-    native().dgeqrf_q_batched(batch, M, N, f64(A), Q, R);
-    return [new NDA(Qs, Q), new NDA(Rs, R)];
+    const dev = isDev(A), temps = [];
+    const Q = alloc(dev, batch * M * L), R = alloc(dev, batch * L * N);
+    native().dgeqrf_q_batched(batch, M, N, view(opF64(A, dev, temps), 0), view(Q, 0), view(R, 0));
+    release(temps);
+    return [wrap(dev, Qs, Q), wrap(dev, Rs, R)];
   };
 
   la.lu_decomp = function lu_decomp(A) {
@@ -228,9 +289,11 @@ function makeLa(NDA, fallback) {
     if (nd_ < 2 || A.shape[nd_ - 2] != A.shape[nd_ - 1]) throw new Error('Last two dimensions must be quadratic.');
     if (!gpuOk(A)) { if (fallback && fallback.lu_decomp) return fallback.lu_decomp(A); throw new Error('nd4hip.lu_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
     const N = A.shape[nd_ - 1], batch = prod(A.shape, 0, nd_ - 2);
-    const LU = new Float64Array(batch * N * N), P = new Int32Array(batch * N);
-    native().dgetrf_batched(batch, N, f64(A), LU, P);
-    return [new NDA(Int32Array.from(A.shape), LU), new NDA(Int32Array.from(A.shape.subarray(0, nd_ - 1)), P)];
+    const dev = isDev(A), temps = [];
+    const LU = alloc(dev, batch * N * N), P = alloc(dev, batch * N, Int32Array);
+    native().dgetrf_batched(batch, N, view(opF64(A, dev, temps), 0), view(LU, 0), view(P, 0));
+    release(temps);
+    return [wrap(dev, A.shape, LU), wrap(dev, A.shape.subarray(0, nd_ - 1), P)];
   };
 
   la.svd_decomp = function svd_decomp(A) {
@@ -240,9 +303,11 @@ function makeLa(NDA, fallback) {
     if (!gpuOk(A)) { if (fallback && fallback.svd_decomp) return fallback.svd_decomp(A); throw new Error('nd4hip.svd_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
     const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], L = Math.min(M, N), batch = prod(A.shape, 0, nd_ - 2);
     const Us = Int32Array.from(A.shape), Vs = Int32Array.from(A.shape); Us[nd_ - 1] = L; Vs[nd_ - 2] = L;
-    const U = new Float64Array(batch * M * L), sv = new Float64Array(batch * L), V = new Float64Array(batch * L * N);
-    la.last_svd_info = native().dgesvdj_batched(batch, M, N, f64(A), U, sv, V);
-    return [new NDA(Us, U), new NDA(Int32Array.from(Us.subarray(0, nd_ - 1)), sv), new NDA(Vs, V)];
+    const dev = isDev(A), temps = [];
+    const U = alloc(dev, batch * M * L), sv = alloc(dev, batch * L), V = alloc(dev, batch * L * N);
+    la.last_svd_info = native().dgesvdj_batched(batch, M, N, view(opF64(A, dev, temps), 0), view(U, 0), view(sv, 0), view(V, 0));
+    release(temps);
+    return [wrap(dev, Us, U), wrap(dev, Us.subarray(0, nd_ - 1), sv), wrap(dev, Vs, V)];
   };
   la.svd_dc = la.svd_decomp;
 
@@ -257,10 +322,12 @@ function makeLa(NDA, fallback) {
     if (T.shape[T.ndim - 1] !== M) throw new Error(`${name}(${tn},Y): Last two dimensions of ${tn} must be quadratic.`);
     if (!gpuOk(T) || !gpuOk(Y)) { if (fallback && fallback[name]) return fallback[name](T, Y); throw new Error(`nd4hip.${name}: dtype is not accelerated.`); }
     const lead = bcastLead([Array.from(T.shape.subarray(0, T.ndim - 2)), Array.from(Y.shape.subarray(0, Y.ndim - 2))], `${name}(${tn},Y): ${tn} and Y not broadcast-compatible.`);
-    const Td = f64(T), Yd = f64(Y), X = new Float64Array(lead.reduce((a, b) => a * b, 1) * M * J);
+    const dev = isDev(T) || isDev(Y), temps = [];
+    const Td = opF64(T, dev, temps), Yd = opF64(Y, dev, temps), X = alloc(dev, lead.reduce((a, b) => a * b, 1) * M * J);
     for (const [cnt, [oT, oY], [sT, sY], b0] of bcastGroupsN(lead, [T.shape.subarray(0, T.ndim - 2), Y.shape.subarray(0, Y.ndim - 2)], [M * M, M * J]))
-      native().dtrsm_batched(upper ? 1 : 0, 0, cnt, M, J, Td.subarray(oT), sT, Yd.subarray(oY), sY, X.subarray(b0 * M * J));
-    return new NDA(Int32Array.from([...lead, M, J]), X);
+      native().dtrsm_batched(upper ? 1 : 0, 0, cnt, M, J, view(Td, oT), sT, view(Yd, oY), sY, view(X, b0 * M * J));
+    release(temps);
+    return wrap(dev, [...lead, M, J], X);
   };
   la.tril_solve = (L, Y) => triSolve(false, 'tril_solve', L, Y);
   la.triu_solve = (U, Y) => triSolve(true, 'triu_solve', U, Y);
@@ -274,17 +341,19 @@ function makeLa(NDA, fallback) {
     if (LU.shape[LU.ndim - 1] != N) throw new Error('Last two dimensions of LU must be quadratic.');
     if (N != I) throw new Error("LU and y don't match.");
     if (N != P.shape[P.ndim - 1]) throw new Error("LU and P don't match.");
-    if (!gpuOk(LU) || !gpuOk(y) || !(P.data instanceof Int32Array)) {
+    if (!gpuOk(LU) || !gpuOk(y) || dtypeOf(P) !== 'int32') {
       if (fallback && fallback.lu_solve) return fallback.lu_solve(LU, P, y);
       throw new Error('nd4hip.lu_solve: dtype is not accelerated.');
     }
     const lLU = Array.from(LU.shape.subarray(0, LU.ndim - 2)), lP = Array.from(P.shape.subarray(0, P.ndim - 1)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
     let lead = bcastLead([lLU, lY], 'LU and y are not broadcast-compatible.');
     lead = bcastLead([lead, lP], 'P is not broadcast-compatible.');
-    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * N * J), LUd = f64(LU), yd = f64(y);
+    const dev = isDev(LU) || isDev(P) || isDev(y), temps = [];
+    const X = alloc(dev, lead.reduce((a, b) => a * b, 1) * N * J), LUd = opF64(LU, dev, temps), Pd = opI32(P, dev, temps), yd = opF64(y, dev, temps);
     for (const [cnt, [oLU, oP, oY], [sLU, sP, sY], b0] of bcastGroupsN(lead, [lLU, lP, lY], [N * N, N, N * J]))
-      native().dgetrs_batched(cnt, N, J, LUd.subarray(oLU), sLU, P.data.subarray(oP), sP, yd.subarray(oY), sY, X.subarray(b0 * N * J));
-    return new NDA(Int32Array.from([...lead, N, J]), X);
+      native().dgetrs_batched(cnt, N, J, view(LUd, oLU), sLU, view(Pd, oP), sP, view(yd, oY), sY, view(X, b0 * N * J));
+    release(temps);
+    return wrap(dev, [...lead, N, J], X);
   };
 
   /* ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ---- */
@@ -303,10 +372,12 @@ function makeLa(NDA, fallback) {
     }
     const lQ = Array.from(Q.shape.subarray(0, Q.ndim - 2)), lR = Array.from(R.shape.subarray(0, R.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
     const lead = bcastLead([lQ, lR, lY], 'Q, R, y are not broadcast-compatible.');
-    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * I * J), Qd = f64(Q), Rd = f64(R), yd = f64(y);
+    const dev = isDev(Q) || isDev(R) || isDev(y), temps = [];
+    const X = alloc(dev, lead.reduce((a, b) => a * b, 1) * I * J), Qd = opF64(Q, dev, temps), Rd = opF64(R, dev, temps), yd = opF64(y, dev, temps);
     for (const [cnt, [oQ, oR, oY], [sQ, sR, sY], b0] of bcastGroupsN(lead, [lQ, lR, lY], [N * M, M * I, N * J]))
-      native().dqrls_batched(cnt, N, M, I, J, Qd.subarray(oQ), sQ, Rd.subarray(oR), sR, yd.subarray(oY), sY, X.subarray(b0 * I * J));
-    return new NDA(Int32Array.from([...lead, I, J]), X);
+      native().dqrls_batched(cnt, N, M, I, J, view(Qd, oQ), sQ, view(Rd, oR), sR, view(yd, oY), sY, view(X, b0 * I * J));
+    release(temps);
+    return wrap(dev, [...lead, I, J], X);
   };
 
   la.svd_lstsq = function svd_lstsq(U, sv, V, y) {
@@ -329,12 +400,14 @@ function makeLa(NDA, fallback) {
     const lU = Array.from(U.shape.subarray(0, U.ndim - 2)), lS = Array.from(sv.shape.subarray(0, sv.ndim - 1)),
           lV = Array.from(V.shape.subarray(0, V.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
     const lead = bcastLead([lU, lV, lY, lS], 'svd_lstsq(U,sv,V, y): U,sv,V,y not broadcast-compatible.');
-    const svd = f64(sv);
-    for (let i = 0; i < svd.length; i++) if (!isFinite(svd[i])) throw new Error('svd_solve(): NaN or Infinity encountered.');   // svd.js:171-172
-    const X = new Float64Array(lead.reduce((a, b) => a * b, 1) * I * J), Ud = f64(U), Vd = f64(V), yd = f64(y);
+    const svh = sv.data;                                     // tiny (batch x M): a device sv is read back once and cached
+    for (let i = 0; i < svh.length; i++) if (!isFinite(svh[i])) throw new Error('svd_solve(): NaN or Infinity encountered.');   // svd.js:171-172
+    const dev = isDev(U) || isDev(sv) || isDev(V) || isDev(y), temps = [];
+    const X = alloc(dev, lead.reduce((a, b) => a * b, 1) * I * J), Ud = opF64(U, dev, temps), svd = opF64(sv, dev, temps), Vd = opF64(V, dev, temps), yd = opF64(y, dev, temps);
     for (const [cnt, [oU, oS, oV, oY], [sU, sS, sV, sY], b0] of bcastGroupsN(lead, [lU, lS, lV, lY], [N * M, M, M * I, N * J]))
-      native().dsvdls_batched(cnt, N, M, I, J, Ud.subarray(oU), sU, svd.subarray(oS), sS, Vd.subarray(oV), sV, yd.subarray(oY), sY, X.subarray(b0 * I * J));
-    return new NDA(Int32Array.from([...lead, I, J]), X);
+      native().dsvdls_batched(cnt, N, M, I, J, view(Ud, oU), sU, view(svd, oS), sS, view(Vd, oV), sV, view(yd, oY), sY, view(X, b0 * I * J));
+    release(temps);
+    return wrap(dev, [...lead, I, J], X);
   };
 
   /* svd.js:66-97: the reference's singularity loop (`for( let r; r < N; r++ )`, :85) never executes, so apart from the
@@ -353,7 +426,7 @@ function makeLa(NDA, fallback) {
 
 const standalone = makeLa(NDArray, null);
 
-/** Patch a loaded nd4js instance in place: the five hot-path functions run on the GPU. Returns nd. */
+/** Patch a loaded nd4js instance in place: the hot-path functions run on the GPU. Returns nd. */
 function install(nd) {
   if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp,
@@ -364,6 +437,8 @@ function install(nd) {
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);
   for (const k of Object.keys(original)) Object.defineProperty(patched, k, {value: acc[k], writable: true, enumerable: true, configurable: true});
+  for (const k of ['to_device', 'to_host', 'synchronize', 'DeviceNDArray'])          // §8f N3 extension, not in the reference
+    Object.defineProperty(patched, k, {value: acc[k], writable: true, enumerable: false, configurable: true});
   if (!target) { try { nd.la = patched; } catch (e) { /* exported getter: caller uses the returned object */ } }
   patched.__nd4hip_original__ = original;
   if (target) return nd;
@@ -373,8 +448,8 @@ function install(nd) {
 }
 
 module.exports = Object.assign(standalone, {
-  NDArray, install, bcastGroups,
-  accelerated: a => !!a && (a.data instanceof Float64Array || a.data instanceof Int32Array),
+  NDArray, DeviceNDArray, install, bcastGroups,
+  accelerated: a => !!a && (isDev(a) || a.data instanceof Float64Array || a.data instanceof Int32Array),
   device_count: () => native().device_count(),
   version: () => native().version(),
 });

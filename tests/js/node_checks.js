@@ -45,6 +45,9 @@ if (mode === 'cpu') {
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
   assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
   assert.ok(/gfx950/.test(la.version()));
+  if (la.device_count() === 0) assert.throws(() => la.to_device(fill(1, [4, 4])), /no HIP device/);
+  assert.throws(() => require(path.join(path.dirname(require.resolve(process.argv[1])), '..', '..', 'nd4js_amd', 'js', 'nd4hip_napi.node')).dgemm_batched(
+    1, 2, 2, 2, new Float64Array(4), 0, {b: {}, o: 0}, 0, new Float64Array(4)), /device buffer from dev_alloc/);
   if (la.device_count() === 0) {
     for (const f of [() => la.matmul2(fill(1, [4, 4]), fill(2, [4, 4])), () => la.qr_decomp(fill(1, [4, 4])),
                      () => la.lu_decomp(fill(1, [4, 4])), () => la.svd_decomp(fill(1, [4, 4]))])
@@ -94,6 +97,31 @@ if (mode === 'gpu') {
   { const m = man.lstsq_svd_rankdef, n = k => { const a = npy('lstsq_svd_rankdef', k); return new la.NDArray(Int32Array.from(a.shape), a.data); };
     const X = la.svd_lstsq(n('U'), n('sv'), n('V'), fill(m.seedY, m.shapeY)), ref = npy('lstsq_svd_rankdef', 'X');
     assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-12); }
+  /* ---- device-resident arrays (SURVEY §8f N3): same kernels, nothing crosses PCIe between calls ---- */
+  { const same = (x, y) => { assert.strictEqual(x.length, y.length); for (let i = 0; i < x.length; i++) assert.ok(Object.is(x[i], y[i]) || x[i] === y[i], `differs at ${i}`); };
+    const A = fill(11, [96, 96]), B = fill(12, [96, 40]), dA = la.to_device(A), dB = la.to_device(B);
+    const dC = la.matmul2(dA, dB);
+    assert.ok(dC instanceof la.DeviceNDArray && dC.onDevice && dC.dtype === 'float64'); assert.deepStrictEqual(Array.from(dC.shape), [96, 40]);
+    same(dC.data, la.matmul2(A, B).data);                                 // lazy D2H; identical kernels -> identical bits
+    assert.strictEqual(dC.data, dC.data);                                  // cached host copy
+    same(la.matmul2(dA, B).data, dC.data); same(la.matmul2(A, dB).data, dC.data);     // mixed residency: host operand uploaded on the way in
+    const [dLU, dP] = la.lu_decomp(dA), [LU, P] = la.lu_decomp(A);
+    assert.ok(dLU.onDevice && dP.onDevice && dP.dtype === 'int32'); same(dLU.data, LU.data); same(dP.data, P.data);
+    const dX = la.lu_solve(dLU, dP, dB); assert.ok(dX.onDevice); same(dX.data, la.lu_solve(LU, P, B).data);
+    same(la.lu_solve([dLU, dP], B).data, dX.data);
+    const [dQ, dR] = la.qr_decomp(dA), [Q, R] = la.qr_decomp(A); same(dQ.data, Q.data); same(dR.data, R.data);
+    same(la.qr_lstsq(dQ, dR, dB).data, la.qr_lstsq(Q, R, B).data);
+    same(la.triu_solve(dR, dB).data, la.triu_solve(R, B).data);
+    const dS = la.svd_decomp(dA), S = la.svd_decomp(A); for (let k = 0; k < 3; k++) same(dS[k].data, S[k].data);
+    same(la.svd_lstsq(dS, dB).data, la.svd_lstsq(S, B).data); same(la.svd_solve(dS, dB).data, la.svd_solve(S, B).data);
+    const chainD = la.matmul(dA, dB, la.to_device(fill(13, [40, 3]))), chainH = la.matmul(A, B, fill(13, [40, 3]));
+    assert.ok(chainD.onDevice); same(chainD.data, chainH.data);
+    const bA = la.to_device(fill(14, [3, 1, 8, 5])), bB = fill(15, [2, 5, 4]);           // broadcast groups with device views at offsets
+    same(la.matmul2(bA, bB).data, la.matmul2(la.to_host(bA), bB).data);
+    const h = la.to_host(dC); assert.ok(h instanceof la.NDArray && h.data === dC.data);
+    dC.dispose(); same(dC.data, h.data);                                   // the cached host copy survives
+    const dD = la.matmul2(dA, dB); dD.dispose(); assert.throws(() => dD.data, /disposed/); assert.throws(() => la.matmul2(dA, dD), /disposed|freed/);
+    la.synchronize(); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }
