@@ -128,6 +128,20 @@ int nd4hip_dsvdls_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_
 int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
 int nd4hip_dgeqrf_q_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
 
+/* ---- qr_decomp_full: replaces src/la/qr.js:27-77 for every shape -----------------
+ * A [batch,M,N] -> Q [batch,M,M], R [batch,M,N]. For M <= N identical to dgeqrf_q. For M > N the Givens-full
+ * convention applies (R_jj >= 0 wherever something was eliminated, rows N.. of R zero) and the trailing M-N
+ * columns of Q are AN orthonormal completion: the reference's own depends on its rotation order, so only
+ * Q[:, 0:N], R and the properties Q Q^T = I, Q R = A are comparable. */
+int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4hip_dgeqrf_full_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+
+/* ---- _qr_decomp_inplace: replaces src/la/qr.js:146-183 (used by opt/_trust_region_solver_tls.js:1126) ----
+ * In place: A [batch,M,N] <- R (upper trapezoid, zeros below), Y [batch,M,L] <- Q^T Y with the full M x M Q of
+ * dgeqrf_full. Rows N.. of the result Y (only when M > N) are expressed in this library's completion basis. */
+int nd4hip_dgeqrf_qty_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y);
+int nd4hip_dgeqrf_qty_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y);
+
 /* ---- svd_decomp: replaces the output contract of src/la/svd.js:25 (= svd_dc.js:883-932) ----------
  * A [batch,M,N] -> U [batch,M,L], sv [batch,L] (>= 0, descending), V [batch,L,N] (rows = right
  * singular vectors), L = min(M,N); one-sided Jacobi with the reference's Jacobi post-processing

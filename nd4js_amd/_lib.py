@@ -48,6 +48,10 @@ SIGNATURES = {
     "nd4hip_dsvdls_batched": (c_int, [ctypes.c_void_p] + [c_i64] * 5 + [c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dgeqrf_q_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
     "nd4hip_dgeqrf_q_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_dgeqrf_full_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_dgeqrf_full_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_dgeqrf_qty_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_i64, c_dp, c_dp]),
+    "nd4hip_dgeqrf_qty_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_i64, c_dp, c_dp]),
     "nd4hip_dgesvdj_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
                                            ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "nd4hip_dgesvdj_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,

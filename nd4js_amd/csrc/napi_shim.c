@@ -44,6 +44,8 @@ static const char* (*p_version)(void);
 static gemm_fn p_dgemm[2];
 static getrf_fn p_dgetrf[2];
 static geqrf_fn p_dgeqrf[2];
+static geqrf_fn p_dgeqrf_full[2];
+static int (*p_dgeqrf_qty[2])(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, double*, double*);
 static gesvdj_fn p_dgesvdj[2];
 static qrls_fn p_dqrls[2];
 static svdls_fn p_dsvdls[2];
@@ -87,6 +89,8 @@ static int load_library(void) {
   SYM2(p_dgemm, "nd4hip_dgemm_batched");
   SYM2(p_dgetrf, "nd4hip_dgetrf_batched");
   SYM2(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
+  SYM2(p_dgeqrf_full, "nd4hip_dgeqrf_full_batched");
+  SYM2(p_dgeqrf_qty, "nd4hip_dgeqrf_qty_batched");
   SYM2(p_dgesvdj, "nd4hip_dgesvdj_batched");
   SYM2(p_dgetrs, "nd4hip_dgetrs_batched");
   SYM2(p_dqrls, "nd4hip_dqrls_batched");
@@ -249,6 +253,30 @@ static napi_value js_dgeqrf(napi_env env, napi_callback_info info) {
   FAIL_IF(p_dgeqrf[A.dev](g_handle, batch, M, N, (const double*)A.p, (double*)Q.p, (double*)R.p));
   return NULL;
 }
+/* dgeqrf_full_batched(batch, M, N, A, Q, R)   (qr_decomp_full, qr.js:27-77: Q is M x M, R is M x N) */
+static napi_value js_dgeqrf_full(napi_env env, napi_callback_info info) {
+  ARGS(6, "dgeqrf_full_batched");
+  int64_t batch, M, N; opnd A, Q, R;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) || F64(3, A) || F64(4, Q) || F64(5, R)) return NULL;
+  NEED(batch >= 0 && M >= 0 && N >= 0 && (size_t)(batch * M * N) <= A.len && (size_t)(batch * M * M) <= Q.len && (size_t)(batch * M * N) <= R.len,
+       "dgeqrf_full_batched: buffer too small");
+  SAME_SIDE(A.dev == Q.dev && Q.dev == R.dev, "dgeqrf_full_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dgeqrf_full[A.dev](g_handle, batch, M, N, (const double*)A.p, (double*)Q.p, (double*)R.p));
+  return NULL;
+}
+/* dgeqrf_qty_batched(batch, M, N, L, A, Y)   (_qr_decomp_inplace, qr.js:146-183: A <- R, Y <- Q^T Y in place) */
+static napi_value js_dgeqrf_qty(napi_env env, napi_callback_info info) {
+  ARGS(6, "dgeqrf_qty_batched");
+  int64_t batch, M, N, L; opnd A, Y;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) || get_i64(env, a[3], &L) || F64(4, A) || F64(5, Y)) return NULL;
+  NEED(batch >= 0 && M >= 0 && N >= 0 && L >= 0 && (size_t)(batch * M * N) <= A.len && (size_t)(batch * M * L) <= Y.len,
+       "dgeqrf_qty_batched: buffer too small");
+  SAME_SIDE(A.dev == Y.dev, "dgeqrf_qty_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dgeqrf_qty[A.dev](g_handle, batch, M, N, L, (double*)A.p, (double*)Y.p));
+  return NULL;
+}
 /* dgesvdj_batched(batch, M, N, A, U, sv, V) -> {sweeps, offnorm} */
 static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
   ARGS(7, "dgesvdj_batched");
@@ -406,6 +434,8 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dgemm_batched", NULL, js_dgemm, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrf_batched", NULL, js_dgetrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},
+    {"dgeqrf_full_batched", NULL, js_dgeqrf_full, NULL, NULL, NULL, napi_default, NULL},
+    {"dgeqrf_qty_batched", NULL, js_dgeqrf_qty, NULL, NULL, NULL, napi_default, NULL},
     {"dgesvdj_batched", NULL, js_dgesvdj, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrs_batched", NULL, js_dgetrs, NULL, NULL, NULL, napi_default, NULL},
     {"dqrls_batched", NULL, js_dqrls, NULL, NULL, NULL, napi_default, NULL},

@@ -267,6 +267,66 @@ extern "C" int nd4hip_dgeqrf_q_batched(nd4hip_handle* h, int64_t batch, int64_t 
   return 0;
 }
 
+// qr_decomp_full (qr.js:27-77) for every shape: Q [M, M], R [M, N]
+extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_full_batched: NULL pointer");
+  return nd4_geqrf_q_ex(h, batch, M, N, A, Q, R, true);
+}
+extern "C" int nd4hip_dgeqrf_full_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nA = (size_t)(batch * M * N), nQ = (size_t)(batch * M * M);
+  DevBuf dA, dQ, dR;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dQ.alloc(nQ * D)); ND4_TRY(dR.alloc(nA * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D));
+  ND4_TRY(nd4hip_dgeqrf_full_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dQ.p, (double*)dR.p));
+  ND4_TRY(d2h(h, Q, dQ.p, nQ * D)); ND4_TRY(d2h(h, R, dR.p, nA * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// _qr_decomp_inplace (qr.js:146-183): A [M, N] <- R, Y [M, L] <- Q^T Y with the full (M x M) Q
+extern "C" int nd4hip_dgeqrf_qty_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_qty_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && L >= 0, "nd4hip_dgeqrf_qty_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && (Y || L == 0), "nd4hip_dgeqrf_qty_batched: NULL pointer");
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, D * (size_t)batch * (size_t)(M * M + M * N + M * L), &p));
+  double* Q = static_cast<double*>(p);
+  double* R = Q + (size_t)batch * M * M;
+  double* Yt = R + (size_t)batch * M * N;
+  ND4_TRY(nd4_geqrf_q_ex(h, batch, M, N, A, Q, R, true));
+  ND4_HIP(hipMemcpyAsync(A, R, D * (size_t)(batch * M * N), hipMemcpyDeviceToDevice, h->stream));
+  if (L > 0) {
+    ND4_TRY(nd4_gemm(h, true, false, M, L, M, 1.0, Q, M, M * M, Y, L, M * L, 0.0, Yt, L, M * L, batch));
+    ND4_HIP(hipMemcpyAsync(Y, Yt, D * (size_t)(batch * M * L), hipMemcpyDeviceToDevice, h->stream));
+  }
+  return 0;
+}
+extern "C" int nd4hip_dgeqrf_qty_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_qty_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && L >= 0, "nd4hip_dgeqrf_qty_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nA = (size_t)(batch * M * N), nY = (size_t)(batch * M * L);
+  DevBuf dA, dY;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dY.alloc(nY * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D));
+  if (nY) ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dgeqrf_qty_batched_dev(h, batch, M, N, L, (double*)dA.p, (double*)dY.p));
+  ND4_TRY(d2h(h, A, dA.p, nA * D));
+  if (nY) ND4_TRY(d2h(h, Y, dY.p, nY * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ SVD
 extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                           double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {

@@ -58,6 +58,7 @@ int nd4_svdls(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, 
 int nd4_getrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t sLU, const int32_t* P, int64_t sP,
               const double* Y, int64_t sY, double* X);
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R, bool full);
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
 

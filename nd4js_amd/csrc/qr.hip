@@ -549,12 +549,23 @@ int apply_block_reflector(nd4hip_handle* h, const QrWs& ws, int batch, int M, in
 
 }  // namespace
 
-int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A, double* Q, double* R) {
+int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
+  return nd4_geqrf_q_ex(h, batch, M, N, A, Q, R, false);
+}
+
+// full = false: qr_decomp (qr.js:80-145): Q [M, L], R [L, N], tall input with the c >= 0 convention of :97-139.
+// full = true : qr_decomp_full (qr.js:27-77): Q [M, M], R [M, N] with the Givens-full convention for every shape
+//               (R_jj >= 0 wherever something was eliminated; det Q = +1 fixes the last row when M <= N). For M > N the
+//               trailing M-N columns of Q are an orthonormal completion (not unique; the reference's is the one its
+//               rotation order happens to produce) and rows N.. of R are zero.
+int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A, double* Q, double* R, bool full) {
   ND4_CHECK_ARG(M64 < (1ll << 30) && N64 < (1ll << 30) && batch64 < 65536, "nd4_geqrf_q: extent out of range");
   const int M = (int)M64, N = (int)N64, batch = (int)batch64;
   const int L = M < N ? M : N;
   const int npanels = (L + NB - 1) / NB;
   const bool tall = M > N;
+  const int Lq = (full && tall) ? M : L;                    // columns of Q
+  const int Lr = (full && tall) ? M : L;                    // rows of R
 
   // ---- workspace carve-up (all per-matrix blocks are multiples of 2 doubles -> 16-B aligned) ----
   QrWs ws;
@@ -562,7 +573,7 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   ws.sV = (long)M * ws.ldv;
   ws.sT = (long)npanels * NB * NB;
   ws.sTau = ws.ldv;
-  const int ncols = (N > L ? N : L);
+  const int ncols = (N > Lq ? N : Lq);
   ws.ldw = ((ncols + 1) / 2) * 2;
   ws.nchunks_max = (M + VTC_ROWS - 1) / VTC_ROWS;
   ws.sChunk = (long)NB * ws.ldw;
@@ -614,40 +625,43 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, con
   }
 
   // ---- R out (tall: top N x N of the work matrix; else already in place, lower part zeroed by the panels) ----
-  if (tall) ND4_TRY(nd4_copy_matrix(h, L, N, W, ld, R, N, batch, sW, (long)L * N));
+  if (tall) {
+    if (Lr > L) ND4_HIP(hipMemsetAsync(R, 0, sizeof(double) * (size_t)batch * Lr * N, h->stream));
+    ND4_TRY(nd4_copy_matrix(h, L, N, W, ld, R, N, batch, sW, (long)Lr * N));
+  }
 
   {   // undo the power-of-two normalisation on R (exact; a no-op when the exponent is 0)
-    const long nR = (long)L * N;
+    const long nR = (long)Lr * N;
     hipLaunchKernelGGL(qr_scale_apply, dim3((unsigned)((nR + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, R, R, nR, exps, +1);
   }
   // ---- Q = H_0 H_1 ... H_{p-1} [I; 0]: block reflectors applied backwards ----
-  const long sQ = (long)M * L;
-  ND4_TRY(nd4_set_identity(h, M, L, Q, L, batch, sQ));
+  const long sQ = (long)M * Lq;
+  ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, batch, sQ));
   for (int pnl = npanels - 1; pnl >= 0; pnl--) {
     const int j0 = pnl * NB;
-    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/0, Q + (long)j0 * L + j0, L, sQ, L - j0));
+    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/0, Q + (long)j0 * Lq + j0, Lq, sQ, Lq - j0));
   }
 
   // ---- reference sign convention ----
-  if (tall) {
+  if (tall && !full) {
     Nd4WsScope scope2(h);
     void* q = nullptr;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * N * N + sizeof(int32_t) * (size_t)batch * N, &q));
     double* LUq = static_cast<double*>(q);
     int32_t* Pq = reinterpret_cast<int32_t*>(LUq + (size_t)batch * N * N);
-    ND4_TRY(nd4_copy_matrix(h, N, N, Q, L, LUq, N, batch, sQ, (long)N * N));
+    ND4_TRY(nd4_copy_matrix(h, N, N, Q, Lq, LUq, N, batch, sQ, (long)N * N));
     ND4_TRY(nd4_getrf_nopivot(h, batch, N, LUq, LUq, Pq));
     hipLaunchKernelGGL(qr_flips_tall, dim3((unsigned)(((long)batch * N + 255) / 256)), dim3(256), 0, h->stream, LUq, N, ws.flips, batch);
   } else
   hipLaunchKernelGGL(qr_flips, dim3((unsigned)batch), dim3(256), 0, h->stream,
-                     R, (long)N, (long)L * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
+                     R, (long)N, (long)Lr * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
   {
     const unsigned gy = (unsigned)(L < 512 ? L : 512);
     hipLaunchKernelGGL(qr_flip_rows, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream,
-                       R, (long)N, (long)L * N, L, N, ws.flips, L);
+                       R, (long)N, (long)Lr * N, L, N, ws.flips, L);
     const unsigned gq = (unsigned)(M < 512 ? M : 512);
     hipLaunchKernelGGL(qr_flip_cols, dim3((unsigned)((L + 255) / 256), gq, (unsigned)batch), dim3(256), 0, h->stream,
-                       Q, (long)L, sQ, M, L, ws.flips, L);
+                       Q, (long)Lq, sQ, M, L, ws.flips, L);
   }
   ND4_HIP(hipGetLastError());
   return 0;

@@ -189,3 +189,25 @@ def svd_lstsq(U, sv, V, Y):
     _lib.check(h.lib.nd4hip_dsvdls_batched_dev(h.ptr, b, N, M, I, J, _p(U), N * M if b > 1 else 0, _p(sv), M if b > 1 else 0,
                                                _p(V), M * I if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
     return X
+
+
+def qr_decomp_full(A):
+    _chk(A, "A")
+    M, N = A.shape[-2:]
+    lead = tuple(A.shape[:-2])
+    Q = torch.empty(lead + (M, M), dtype=torch.float64, device=A.device)
+    R = torch.empty(lead + (M, N), dtype=torch.float64, device=A.device)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgeqrf_full_batched_dev(h.ptr, _batch(lead), M, N, _p(A), _p(Q), _p(R)))
+    return Q, R
+
+
+def qr_decomp_inplace(A, Y):
+    """_qr_decomp_inplace (qr.js:146-183) on device tensors, in place: A <- R, Y <- Q^T Y"""
+    _chk(A, "A"), _chk(Y, "Y")
+    if tuple(A.shape[:-1]) != tuple(Y.shape[:-1]):
+        raise ValueError("Assertion failed.")
+    M, N = A.shape[-2:]
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgeqrf_qty_batched_dev(h.ptr, _batch(A.shape[:-2]), M, N, Y.shape[-1], _p(A), _p(Y)))
+    return A, Y

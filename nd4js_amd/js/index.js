@@ -283,6 +283,33 @@ function makeLa(NDA, fallback) {
     return [wrap(dev, Qs, Q), wrap(dev, Rs, R)];
   };
 
+  la.qr_decomp_full = function qr_decomp_full(A) {         // qr.js:27-77: Q [..., M, M], R [..., M, N]
+    A = asarray(A);
+    if (A.ndim < 2) throw new Error('A must be at least 2D.');
+    if (!gpuOk(A)) { if (fallback && fallback.qr_decomp_full) return fallback.qr_decomp_full(A); throw new Error('nd4hip.qr_decomp_full: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], batch = prod(A.shape, 0, nd_ - 2);
+    const Qs = Int32Array.from(A.shape); Qs[nd_ - 1] = M;
+    const dev = isDev(A), temps = [];
+    const Q = alloc(dev, batch * M * M), R = alloc(dev, batch * M * N);
+    native().dgeqrf_full_batched(batch, M, N, view(opF64(A, dev, temps), 0), view(Q, 0), view(R, 0));
+    release(temps);
+    return [wrap(dev, Qs, Q), wrap(dev, A.shape, R)];
+  };
+
+  /* qr.js:146-183, same signature and in-place semantics: A (M x N at A_off) <- R, Y (M x L at Y_off) <- Q^T Y.
+     A and Y are Float64Arrays; the reference's assertions are kept (its only message is 'Assertion failed.'). */
+  la._qr_decomp_inplace = function _qr_decomp_inplace(M, N, L, A, A_off, Y, Y_off) {
+    for (const v of [M, N, L, A_off, Y_off]) if (v % 1 !== 0 || !(0 <= v)) throw new Error('Assertion failed.');
+    if (!(A instanceof Float64Array) || !(Y instanceof Float64Array)) {
+      if (fallback && fallback._qr_decomp_inplace) return fallback._qr_decomp_inplace(M, N, L, A, A_off, Y, Y_off);
+      throw new Error('nd4hip._qr_decomp_inplace: only Float64Array storage is accelerated.');
+    }
+    if (!(M * N <= A.length - A_off)) throw new Error('Assertion failed.');
+    if (!(M * L <= Y.length - Y_off)) throw new Error('Assertion failed.');
+    if (M === 0 || N === 0) return;
+    native().dgeqrf_qty_batched(1, M, N, L, A.subarray(A_off, A_off + M * N), Y.subarray(Y_off, Y_off + M * L));
+  };
+
   la.lu_decomp = function lu_decomp(A) {
     A = asarray(A);
     const nd_ = A.ndim;
@@ -429,7 +456,7 @@ const standalone = makeLa(NDArray, null);
 /** Patch a loaded nd4js instance in place: the hot-path functions run on the GPU. Returns nd. */
 function install(nd) {
   if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
-  const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp,
+  const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp, qr_decomp_full: nd.la.qr_decomp_full,
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
                     qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve};

@@ -146,6 +146,36 @@ def qr_decomp(A, device=None):
     return Q, R
 
 
+def qr_decomp_full(A, device=None):
+    """qr.js:27-77: Q [..., M, M], R [..., M, N]."""
+    A = _asarray(A, "qr_decomp_full(A)")
+    if A.ndim < 2:
+        raise ValueError("A must be at least 2D.")
+    M, N = A.shape[-2:]
+    batch = int(np.prod(A.shape[:-2], dtype=np.int64))
+    Q = np.empty(A.shape[:-2] + (M, M))
+    R = np.empty(A.shape[:-2] + (M, N))
+    h = _lib.handle(device)
+    _lib.check(h.lib.nd4hip_dgeqrf_full_batched(h.ptr, batch, M, N, _ptr(A), _ptr(Q), _ptr(R)))
+    return Q, R
+
+
+def qr_decomp_inplace(A, Y, device=None):
+    """_qr_decomp_inplace (qr.js:146-183) on writable float64 arrays A [..., M, N] and Y [..., M, L] with equal leading
+    dims: A <- R, Y <- Q^T Y, in place like the reference. Returns (A, Y)."""
+    for a, n in ((A, "A"), (Y, "Y")):
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable):
+            raise TypeError("qr_decomp_inplace: %s must be a writable C-contiguous float64 ndarray" % n)
+    if A.ndim < 2 or Y.ndim < 2 or A.shape[:-1] != Y.shape[:-1]:
+        raise ValueError("Assertion failed.")                      # the reference's only message (qr.js:148-166)
+    M, N = A.shape[-2:]
+    L = Y.shape[-1]
+    batch = int(np.prod(A.shape[:-2], dtype=np.int64))
+    h = _lib.handle(device)
+    _lib.check(h.lib.nd4hip_dgeqrf_qty_batched(h.ptr, batch, M, N, L, _ptr(A), _ptr(Y)))
+    return A, Y
+
+
 def lu_decomp(A, device=None):
     A = _asarray(A, "lu_decomp(A)")
     if A.ndim < 2 or A.shape[-1] != A.shape[-2]:

@@ -43,6 +43,7 @@ def lib():
         L.nd4o_tril_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_triu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_lu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _ip, _i64, _dp, _i64, _dp]
+        L.nd4o_qr_decomp_inplace.argtypes = [_i64, _i64, _i64, _dp, _dp]
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
         L.nd4o_svd_lstsq.restype = ctypes.c_int
@@ -217,3 +218,14 @@ def svd_lstsq(U, sv, V, Y):
     if rc:
         raise ValueError("svd_solve(): NaN or Infinity encountered.")
     return X
+
+
+def qr_decomp_inplace(A, Y):
+    """qr.js:146-183 on copies: returns (R [..., M, N], Q^T Y [..., M, L])"""
+    A, Y = _f64(A).copy(), _f64(Y).copy()
+    M, N = A.shape[-2:]
+    L = Y.shape[-1]
+    a2, y2 = A.reshape(-1, M, N), Y.reshape(-1, M, L)
+    for b in range(a2.shape[0]):
+        lib().nd4o_qr_decomp_inplace(M, N, L, _d(a2[b]), _d(y2[b]))
+    return A, Y

@@ -233,6 +233,30 @@ if (what === 'lstsq') {
   caseSvdLs('solve_svd_rankdef', 'svd_solve', 117, [16, 16], 118, [16, 2], true);   // the reference returns (its rank loop never runs)
 }
 
+if (what === 'inplace') {
+  /* SURVEY §8f N2: qr_decomp_full for every shape (qr.js:27-77) and _qr_decomp_inplace (qr.js:146-183). The bundle does
+     not export _qr_decomp_inplace; the expected values are the ones the reference's own test compares it with
+     (qr_test.js:213-225): R of qr_decomp_full and matmul2(Q.T, Y). */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const zeros10 = (a, seed) => { const m = fill(seed, a.length); for (let i = 0; i < a.length; i++) if (m[i] > 0.8) a[i] = 0; return a; };
+  const caseInplace = (name, seedA, shapeA, seedY, L, sparse) => {
+    const [M, N] = shapeA, a = fill(seedA, M * N);
+    if (sparse) zeros10(a, seedA + 1000);
+    const Y = NDA([M, L], fill(seedY, M * L));
+    const [Q, R] = nd.la.qr_decomp_full(NDA(shapeA, a));
+    const QtY = nd.la.matmul2(Q.T, Y);
+    record(name, {op: 'qr_decomp_inplace', seedA, shapeA, seedY, L, sparse: !!sparse},
+           {Q: [Q.data, Array.from(Q.shape)], R: [R.data, Array.from(R.shape)], QtY: [QtY.data, Array.from(QtY.shape)]});
+  };
+  caseInplace('inplace_qr_24x24', 121, [24, 24], 122, 3);
+  caseInplace('inplace_qr_20x45', 123, [20, 45], 124, 7);
+  caseInplace('inplace_qr_45x20', 125, [45, 20], 126, 5);
+  caseInplace('inplace_qr_sparse_33x33', 127, [33, 33], 128, 1, true);
+  caseInplace('inplace_qr_1x1', 129, [1, 1], 130, 2);
+  caseInplace('inplace_qr_70x70', 131, [70, 70], 132, 40);
+  caseInplace('inplace_qr_100x37', 133, [100, 37], 134, 9);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

@@ -229,6 +229,25 @@ void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_
   }
 }
 
+/* src/la/qr.js:146-183 _qr_decomp_inplace: Givens elimination of A (M x N) in place, the same rotations applied to the
+ * rows of Y (M x L). The bundle /root/reference/dist/nd.js does not export this function, so it is pinned through the
+ * reference's own test oracle (qr_test.js:213-225): A == R and Y == Q^T Y of qr_decomp_full. */
+void nd4o_qr_decomp_inplace(int64_t M, int64_t N, int64_t L, double* A, double* Y) {
+  for (int64_t i = 1; i < M; i++)
+    for (int64_t j = 0; j < N && j < i; j++) {
+      const int64_t ij = N * i + j, jj = N * j + j;
+      const double A_ij = A[ij];
+      if (A_ij == 0.0) continue;
+      double c, s, norm;
+      nd4o_giv_rot_qr(A[jj], A_ij, &c, &s, &norm);
+      A[ij] = 0.0;
+      if (s == 0.0) continue;
+      A[jj] = norm;
+      giv_rot_rows(A, N - 1 - j, jj + 1, ij + 1, c, s);
+      giv_rot_rows(Y, L, L * j, L * i, c, s);
+    }
+}
+
 /* src/la/qr.js:186-273 qr_lstsq core (:232-241): x[0:L] = Q^T y accumulated k-innermost, then _triu_solve(L,I,J) */
 void nd4o_qr_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* Q, int64_t sQ, const double* R, int64_t sR,
                    const double* Y, int64_t sY, double* X) {

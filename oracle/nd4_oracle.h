@@ -52,6 +52,9 @@ void nd4o_triu_solve(int64_t batch, int64_t M, int64_t O, const double* U, int64
 void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU, const int32_t* P, int64_t strideP,
                    const double* Y, int64_t strideY, double* X);
 
+/* src/la/qr.js:146-183 _qr_decomp_inplace on one matrix: A [M,N] <- R, Y [M,L] <- Q^T Y */
+void nd4o_qr_decomp_inplace(int64_t M, int64_t N, int64_t L, double* A, double* Y);
+
 /* src/la/qr.js:186-273 qr_lstsq core: Q [N,M], R [M,I], Y [N,J] -> X [I,J] (strides in doubles, 0 = broadcast) */
 void nd4o_qr_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* Q, int64_t strideQ, const double* R, int64_t strideR,
                    const double* Y, int64_t strideY, double* X);

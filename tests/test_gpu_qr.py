@@ -122,3 +122,82 @@ def test_extreme_scales_like_the_scaled_givens(la, scale):
     rq, rr = oracle.qr_decomp(a)
     assert np.isfinite(r).all() and np.isfinite(q).all()
     assert relerr(r / scale, rr / scale) <= 1e-12 and relerr(q, rq) <= 1e-12
+
+
+# ---- qr_decomp_full for every shape (qr.js:27-77) and _qr_decomp_inplace (qr.js:146-183) ----
+def _inplace_input(g):
+    M, N = g.shapeA
+    a = rng.matrix(g.seedA, M, N)
+    if g.sparse:
+        a[rng.matrix(g.seedA + 1000, M, N) > 0.8] = 0.0
+    return a, rng.matrix(g.seedY, M, g.L)
+
+
+@pytest.mark.parametrize("name", golden_cases(op="qr_decomp_inplace"))
+def test_qr_decomp_full_all_shapes_golden(golden, name):
+    from nd4js_amd import la
+    g = golden(name)
+    a, _ = _inplace_input(g)
+    M, N = a.shape
+    q, r = la.qr_decomp_full(a)
+    assert q.shape == (M, M) and r.shape == (M, N)
+    eps = 2.0 ** -52
+    K = min(M, N)
+    scale = max(np.linalg.norm(a), 1e-300)
+    assert np.abs(r - g["R"]).max() <= 64 * eps * max(M, N) * scale
+    assert np.abs(q[:, :K] - g["Q"][:, :K]).max() <= 1e-11                     # the unique part of Q
+    assert np.array_equal(np.tril(r, -1), np.zeros_like(r))
+    assert np.abs(q @ q.T - np.eye(M)).max() <= 8 * eps * M                  # qr_test.js:186
+    assert np.linalg.norm(q @ r - a) <= 16 * eps * max(M, N) * scale
+    if M > N:                                                                  # completion: orthogonal to range(A), any basis
+        assert np.abs(q[:, N:].T @ a).max() <= 64 * eps * M * scale
+
+
+@pytest.mark.parametrize("name", golden_cases(op="qr_decomp_inplace"))
+def test_qr_decomp_inplace_golden(golden, name):
+    from nd4js_amd import la
+    g = golden(name)
+    a, y = _inplace_input(g)
+    M, N = a.shape
+    a0, y0 = a.copy(), y.copy()
+    ra, ry = la.qr_decomp_inplace(a, y)
+    assert ra is a and ry is y                                                  # in place, like the reference
+    eps = 2.0 ** -52
+    scale = max(np.linalg.norm(a0), 1e-300)
+    assert np.array_equal(np.tril(a, -1), np.zeros_like(a))                    # toBeUpperTriangular (qr_test.js:223)
+    assert np.abs(a - g["R"]).max() <= 64 * eps * max(M, N) * scale            # toBeAllCloseTo(R)        (:224)
+    K = min(M, N) if M > N else M
+    assert np.abs(y[:K] - g["QtY"][:K]).max() <= 1e-11 * max(np.abs(y0).max(), 1)      # == Q^T Y (:225) on the unique rows
+    # rows N.. (tall only) live in this library's completion basis: same energy per column, and Q [R; y] reproduces [A, Y]
+    assert np.allclose(np.linalg.norm(y, axis=0), np.linalg.norm(y0, axis=0), rtol=1e-12, atol=1e-13)
+    ro, yo = oracle.qr_decomp_inplace(a0, y0)
+    assert np.allclose(np.linalg.norm(y[K:], axis=0), np.linalg.norm(yo[K:], axis=0), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("M,N,L", [(1, 1, 1), (5, 9, 2), (64, 64, 1), (200, 200, 17), (300, 120, 8), (1024, 1024, 4)])
+def test_qr_decomp_inplace_vs_oracle_and_device(M, N, L):
+    import torch
+    from nd4js_amd import dev
+    a = rng.matrix(4100 + M, 2, M, N)
+    y = rng.matrix(4200 + L, 2, M, L)
+    ad, yd = torch.from_numpy(a).cuda(), torch.from_numpy(y).cuda()
+    dev.qr_decomp_inplace(ad, yd)
+    r, qty = ad.cpu().numpy(), yd.cpu().numpy()
+    K = min(M, N)
+    if M <= 300:
+        ro, yo = oracle.qr_decomp_inplace(a, y)
+        assert np.abs(r - ro).max() <= 1e-12 * np.abs(a).max() * max(M, N)
+        assert np.abs(qty[:, :K] - yo[:, :K]).max() <= 1e-11 * M
+    # least-squares use (what opt/_trust_region_solver_tls.js:1126 does with it): R x = (Q^T y)[0:N] solves min |A x - y|
+    if M >= N:
+        x = np.linalg.solve(r[:, :N, :N], qty[:, :N])
+        ref = np.linalg.pinv(a) @ y
+        assert np.abs(x - ref).max() <= 1e-9 * max(np.linalg.cond(a[0]), np.linalg.cond(a[1]))
+
+
+def test_qr_decomp_inplace_rejects_like_reference():
+    from nd4js_amd import la
+    with pytest.raises(ValueError, match="Assertion failed"):
+        la.qr_decomp_inplace(np.ones((3, 2)), np.ones((4, 1)))
+    with pytest.raises(TypeError):
+        la.qr_decomp_inplace(np.ones((3, 2), dtype=np.float32), np.ones((3, 1)))

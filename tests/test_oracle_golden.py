@@ -159,3 +159,20 @@ def test_lstsq_errors():
         oracle.qr_lstsq(np.ones((3, 3)), np.ones((3, 5)), np.ones((3, 1)))
     with pytest.raises(ValueError, match="NaN or Infinity"):
         oracle.svd_lstsq(np.eye(2), np.array([1.0, np.nan]), np.eye(2), np.ones((2, 1)))
+
+
+# ---- _qr_decomp_inplace (qr.js:146-183), pinned through the reference's own test oracle ----
+@pytest.mark.parametrize("name", golden_cases(op="qr_decomp_inplace"))
+def test_qr_decomp_inplace_matches_reference_test_oracle(golden, name):
+    g = golden(name)
+    M, N = g.shapeA
+    a = rng.matrix(g.seedA, M, N)
+    if g.sparse:
+        a[rng.matrix(g.seedA + 1000, M, N) > 0.8] = 0.0
+    y = rng.matrix(g.seedY, M, g.L)
+    r, qty = oracle.qr_decomp_inplace(a, y)
+    assert np.array_equal(np.tril(r, -1), np.zeros_like(r))             # toBeUpperTriangular (qr_test.js:223)
+    assert np.array_equal(r, g["R"])                                      # same rotations as qr_decomp_full -> same bits
+    assert np.abs(qty - g["QtY"]).max() <= 1e-13 * max(np.abs(y).max(), 1) * M
+    qf, rf = oracle.qr_decomp_full(a)                                     # and the oracle's own qr_decomp_full is the reference's
+    assert np.array_equal(qf, g["Q"]) and np.array_equal(rf, g["R"])
