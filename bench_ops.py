@@ -50,6 +50,13 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
         f = 2.0 * N * N * N
         out["lu_solve%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
                                  "rhs_columns": N, "algorithmic_flops": f}
+        # N4: Cholesky of S = B B^T + N I (formed on the device), N^3/3 flop
+        S = dev.gemm_ex(False, True, 1.0, A, A, 0.0, torch.empty_like(A), N, N, N, N, N, N)
+        S.diagonal().add_(float(N))
+        ms = _time(lambda: dev.cholesky_decomp(S), h, 5)
+        f = N ** 3 / 3.0
+        out["cholesky%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                                 "algorithmic_flops": f}
         A9 = dev.fill_uniform(9, (N, N))
         info = {}
         ms = _time(lambda: dev.svd_decomp(A9, info=info), h, 1)

@@ -31,6 +31,7 @@ typedef struct nd4hip_handle nd4hip_handle;
 #define ND4HIP_ERR_HIP      -2   /* HIP runtime error (message has the hipError string) */
 #define ND4HIP_ERR_NOCONV   -3   /* Jacobi SVD hit the sweep limit */
 #define ND4HIP_ERR_NODEV    -4   /* no usable GPU */
+#define ND4HIP_ERR_SINGULAR -5   /* Cholesky met a NaN pivot: 'Matrix contains NaNs or is (near) singular.' */
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
 int  nd4hip_device_count(void);
@@ -98,6 +99,22 @@ int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_diag, int64_t
                              const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X);
 int nd4hip_dtrsm_batched    (nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
                              const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X);
+
+/* ---- cholesky_decomp: replaces src/la/cholesky.js:51-71 (kernel :27-48)    -------------
+ * S [batch,N,N] symmetric positive definite, only the lower triangle is read (:65-67) -> L [batch,N,N] lower
+ * triangular with exact zeros above the diagonal, S = L L^T. A NaN pivot in any matrix returns ND4HIP_ERR_SINGULAR
+ * with the reference's message (:43-44); L then holds NaNs from that pivot on. Both forms synchronise once
+ * (a batch-sized flag read-back) to decide that. */
+int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L);
+int nd4hip_dpotrf_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L);
+
+/* ---- cholesky_solve: replaces src/la/cholesky.js:74-150 ------------------------------------------------
+ * X [batch,N,J] = L^-T L^-1 Y (forward substitution tri.js:45-71, then backward with the transpose :100-125).
+ * strides in elements, 0 = broadcast. */
+int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
+                              const double* Y, int64_t strideY, double* X);
+int nd4hip_dpotrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
+                              const double* Y, int64_t strideY, double* X);
 
 /* ---- qr_lstsq: replaces src/la/qr.js:186-273 -------------------------------------
  * X [batch,I,J] = R[0:L,0:L]^-1 (Q^T Y)[0:L,:], L = min(M,I), rows L..I-1 zero; Q [batch,N,M], R [batch,M,I]

@@ -42,6 +42,10 @@ SIGNATURES = {
     "nd4hip_dgetrs_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_i64, ctypes.c_void_p, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dtrsm_batched_dev": (c_int, [ctypes.c_void_p, c_int, c_int, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dtrsm_batched": (c_int, [ctypes.c_void_p, c_int, c_int, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
+    "nd4hip_dpotrf_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp]),
+    "nd4hip_dpotrf_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp]),
+    "nd4hip_dpotrs_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
+    "nd4hip_dpotrs_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dqrls_batched_dev": (c_int, [ctypes.c_void_p] + [c_i64] * 5 + [c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dqrls_batched": (c_int, [ctypes.c_void_p] + [c_i64] * 5 + [c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dsvdls_batched_dev": (c_int, [ctypes.c_void_p] + [c_i64] * 5 + [c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),

@@ -41,6 +41,7 @@ struct GemmArgs {
   long lda, ldb, ldc, sA, sB, sC;
   double alpha, beta;
   int tiles_m, tiles_n;
+  int lower;          // 1: skip tiles that lie entirely above the diagonal (symmetric rank-k updates)
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   const int tm = first_m + (wg % per_group) % gsz;
   const int tn = (wg % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (g.lower && n0 > m0 + BM - 1) return;          // whole workgroup, before any barrier
 
   const long bz = blockIdx.y;
   const double* __restrict__ A = g.A + bz * g.sA;
@@ -231,7 +233,7 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.alpha = alpha; g.beta = beta;
+  g.alpha = alpha; g.beta = beta; g.lower = 0;
   g.tiles_m = (int)((M + BM - 1) / BM); g.tiles_n = (int)((N + BN - 1) / BN);
   ND4_CHECK_ARG((int64_t)g.tiles_m * g.tiles_n < (1ll << 31), "nd4_gemm: too many tiles");
   auto even = [](int64_t v) { return (v & 1) == 0; };
@@ -242,4 +244,20 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
                    even(transA ? M : K) && even(transB ? K : N);
   if (transA) return transB ? launch<true, true>(h, g, vec, batch) : launch<true, false>(h, g, vec, batch);
   return transB ? launch<false, true>(h, g, vec, batch) : launch<false, false>(h, g, vec, batch);
+}
+
+// C[lower tiles] = alpha * A A^T + beta * C for A [N, K] (row-major, lda): every 128x128 tile that touches the diagonal
+// or lies below it is computed in full, tiles strictly above are skipped (their C entries are left untouched).
+int nd4_syrk_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int64_t sA,
+                   double beta, double* C, int64_t ldc, int64_t sC, int64_t batch) {
+  if (N <= 0 || batch <= 0) return 0;
+  ND4_CHECK_ARG(K >= 0 && N < (1 << 30) && K < (1 << 30), "nd4_syrk_lower: extent out of range");
+  ND4_CHECK_ARG(batch <= 65535, "nd4_syrk_lower: batch %lld exceeds 65535 per launch", (long long)batch);
+  GemmArgs g;
+  g.A = A; g.B = A; g.C = C; g.M = (int)N; g.N = (int)N; g.K = (int)K;
+  g.lda = lda; g.ldb = lda; g.ldc = ldc; g.sA = sA; g.sB = sA; g.sC = sC;
+  g.alpha = alpha; g.beta = beta; g.lower = 1;
+  g.tiles_m = (int)((N + BM - 1) / BM); g.tiles_n = g.tiles_m;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (sA & 1) == 0 && (K & 1) == 0;
+  return launch<false, true>(h, g, vec, batch);
 }

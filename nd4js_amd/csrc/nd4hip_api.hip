@@ -243,6 +243,69 @@ extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   return 0;
 }
 
+// ---- Cholesky: cholesky_decomp (cholesky.js:51-71), cholesky_solve (:74-150)   
+extern "C" int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dpotrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(S && L, "nd4hip_dpotrf_batched: NULL pointer");
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(int) * (size_t)batch, &p));
+  int* flags = static_cast<int*>(p);
+  ND4_TRY(nd4_potrf(h, batch, N, S, L, flags));
+  // the reference throws on the first NaN pivot (cholesky.js:43-44): one small read-back decides it
+  void* hp = nullptr;
+  ND4_TRY(nd4_pinned(h, sizeof(int) * (size_t)batch, &hp));
+  int* host = static_cast<int*>(hp);
+  ND4_HIP(hipMemcpyAsync(host, flags, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  for (int64_t b = 0; b < batch; b++)
+    if (host[b]) { nd4_set_error("Matrix contains NaNs or is (near) singular."); return ND4HIP_ERR_SINGULAR; }
+  return 0;
+}
+extern "C" int nd4hip_dpotrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dpotrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)(batch * N * N);
+  DevBuf dS, dL;
+  ND4_TRY(dS.alloc(n * D)); ND4_TRY(dL.alloc(n * D));
+  ND4_TRY(h2d(h, dS.p, S, n * D));
+  ND4_TRY(nd4hip_dpotrf_batched_dev(h, batch, N, (const double*)dS.p, (double*)dL.p));
+  ND4_TRY(d2h(h, L, dL.p, n * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
+                                         const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dpotrs_batched: negative extent");
+  ND4_CHECK_ARG((strideL == 0 || strideL >= N * N) && (strideY == 0 || strideY >= N * J),
+                "nd4hip_dpotrs_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(L && Y && X, "nd4hip_dpotrs_batched: NULL pointer");
+  return nd4_potrs(h, batch, N, J, L, strideL, Y, strideY, X);
+}
+extern "C" int nd4hip_dpotrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
+                                     const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dpotrs_batched: negative extent");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nL = (size_t)(strideL ? (batch - 1) * strideL + N * N : N * N);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
+  const size_t nX = (size_t)(batch * N * J);
+  DevBuf dL, dY, dX;
+  ND4_TRY(dL.alloc(nL * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  ND4_TRY(h2d(h, dL.p, L, nL * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dpotrs_batched_dev(h, batch, N, J, (const double*)dL.p, strideL, (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ QR
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");

@@ -51,6 +51,13 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
 int nd4_getrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4_getrf_nopivot(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4_trsm(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t M, int64_t J, const double* T, int64_t sT, double* X);
+int nd4_syrk_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int64_t sA,
+                   double beta, double* C, int64_t ldc, int64_t sC, int64_t batch);
+int nd4_trsm_ld(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t M, int64_t J, const double* T, int64_t ldT, int64_t sT,
+                double* X, int64_t sX);
+int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M, int64_t J, const double* T, int64_t ldT, int64_t sT, double* X, int64_t sX);
+int nd4_potrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L, int* flags);
+int nd4_potrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t sL, const double* Y, int64_t sY, double* X);
 int nd4_qrls(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* Q, int64_t sQ,
              const double* R, int64_t sR, const double* Y, int64_t sY, double* X);
 int nd4_svdls(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, const double* U, int64_t sU,

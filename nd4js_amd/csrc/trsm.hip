@@ -15,7 +15,8 @@ constexpr int TB = 32;
 
 template <bool UPPER>
 __global__ __launch_bounds__(256) void tri_block_solve(const double* __restrict__ Tm, int M, long sT, double* __restrict__ Xm, int J, long sX,
-                                                        int r0, int nbt, int unit) {   // M = leading dimension of T
+                                                        int r0, int nbt, int unit, int trans) {   // M = leading dimension of T
+  // trans: the triangle is the TRANSPOSE of what is stored (UPPER + trans = L^T of a stored lower L, tri.js:100-125)
   __shared__ double s_t[TB][TB + 1];
   const double* T = Tm + blockIdx.y * sT;
   double* X = Xm + blockIdx.y * sX;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void tri_block_solve(const double* __restrict_
     double v = (i == j) ? 1.0 : 0.0;                               // identity padding beyond nbt
     if (i < nbt && j < nbt) {
       const bool tri = UPPER ? (j >= i) : (j <= i);
-      v = tri ? T[(long)(r0 + i) * M + r0 + j] : 0.0;
+      v = tri ? (trans ? T[(long)(r0 + j) * M + r0 + i] : T[(long)(r0 + i) * M + r0 + j]) : 0.0;
       if (unit && i == j) v = 1.0;
     }
     s_t[i][j] = v;
@@ -85,8 +86,8 @@ int nd4_trsm_ld(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t 
   for (int bi = 0; bi < nblocks; bi++) {
     const int b = upper ? nblocks - 1 - bi : bi;
     const int r0 = b * TB, nbt = M - r0 < TB ? M - r0 : TB;
-    if (upper) hipLaunchKernelGGL(tri_block_solve<true>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, unit ? 1 : 0);
-    else       hipLaunchKernelGGL(tri_block_solve<false>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, unit ? 1 : 0);
+    if (upper) hipLaunchKernelGGL(tri_block_solve<true>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, unit ? 1 : 0, 0);
+    else       hipLaunchKernelGGL(tri_block_solve<false>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, unit ? 1 : 0, 0);
     ND4_HIP(hipGetLastError());
     if (upper) {
       if (r0 > 0)      // rows above the block
@@ -97,6 +98,24 @@ int nd4_trsm_ld(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t 
         ND4_TRY(nd4_gemm(h, false, false, below, J, nbt, -1.0, T + (long)(r0 + nbt) * ldT + r0, ldT, sT, X + (long)r0 * J, J, sX,
                          1.0, X + (long)(r0 + nbt) * J, J, sX, batch));
     }
+  }
+  return 0;
+}
+
+// in place: X <- L^-T X for a stored LOWER triangle L (non-unit diagonal): _tril_t_solve, tri.js:100-125
+int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M64, int64_t J64, const double* T, int64_t ldT64, int64_t sT, double* X, int64_t sX64) {
+  ND4_CHECK_ARG(M64 < (1ll << 30) && J64 < (1ll << 30) && batch < 65536, "nd4_trsm_t: extent out of range");
+  const int M = (int)M64, J = (int)J64, ldT = (int)ldT64;
+  if (M == 0 || J == 0 || batch == 0) return 0;
+  const long sX = (long)sX64;
+  const dim3 grid((unsigned)((J + 255) / 256), (unsigned)batch);
+  const int nblocks = (M + TB - 1) / TB;
+  for (int b = nblocks - 1; b >= 0; b--) {
+    const int r0 = b * TB, nbt = M - r0 < TB ? M - r0 : TB;
+    hipLaunchKernelGGL(tri_block_solve<true>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, 0, 1);
+    ND4_HIP(hipGetLastError());
+    if (r0 > 0)      // rows above: X[0:r0] -= L[block, 0:r0]^T X[block]
+      ND4_TRY(nd4_gemm(h, true, false, r0, J, nbt, -1.0, T + (long)r0 * ldT, ldT, sT, X + (long)r0 * J, J, sX, 1.0, X, J, sX, batch));
   }
   return 0;
 }

@@ -211,3 +211,37 @@ def qr_decomp_inplace(A, Y):
     h = _h(A)
     _lib.check(h.lib.nd4hip_dgeqrf_qty_batched_dev(h.ptr, _batch(A.shape[:-2]), M, N, Y.shape[-1], _p(A), _p(Y)))
     return A, Y
+
+
+def cholesky_decomp(S):
+    """device-resident cholesky_decomp (cholesky.js:51-71); one flag read-back decides the reference's singularity error"""
+    _chk(S, "S")
+    N = S.shape[-1]
+    if S.dim() < 2 or S.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    L = torch.empty_like(S)
+    h = _h(S)
+    try:
+        _lib.check(h.lib.nd4hip_dpotrf_batched_dev(h.ptr, _batch(S.shape[:-2]), N, _p(S), _p(L)))
+    except _lib.Nd4HipError as e:
+        if e.code == -5:
+            raise ValueError("Matrix contains NaNs or is (near) singular.")
+        raise
+    return L
+
+
+def cholesky_solve(L, Y):
+    _chk(L, "L"), _chk(Y, "Y")
+    N, J = Y.shape[-2:]
+    if L.shape[-1] != L.shape[-2]:
+        raise ValueError("Last two dimensions of L must be quadratic.")
+    if L.shape[-1] != N:
+        raise ValueError("L and y don't match.")
+    lead = tuple(Y.shape[:-2])
+    if tuple(L.shape[:-2]) != lead:
+        raise ValueError("Shapes are not broadcast-compatible.")       # general broadcasting: host wrapper (la.py)
+    X = torch.empty_like(Y)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dpotrs_batched_dev(h.ptr, b, N, J, _p(L), N * N if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
+    return X

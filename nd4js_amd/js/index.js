@@ -383,6 +383,38 @@ function makeLa(NDA, fallback) {
     return wrap(dev, [...lead, N, J], X);
   };
 
+  /* ---- SURVEY §8f N4: Cholesky (csrc/chol.hip) ---- */
+  la.cholesky_decomp = function cholesky_decomp(S) {       // cholesky.js:51-71
+    S = asarray(S);
+    const nd_ = S.ndim;
+    if (nd_ < 2 || S.shape[nd_ - 2] != S.shape[nd_ - 1]) throw new Error('Last two dimensions must be quadratic.');
+    if (!gpuOk(S)) { if (fallback && fallback.cholesky_decomp) return fallback.cholesky_decomp(S); throw new Error('nd4hip.cholesky_decomp: dtype ' + dtypeOf(S) + ' is not accelerated.'); }
+    const N = S.shape[nd_ - 1], batch = prod(S.shape, 0, nd_ - 2), dev = isDev(S), temps = [];
+    const L = alloc(dev, batch * N * N);
+    try { native().dpotrf_batched(batch, N, view(opF64(S, dev, temps), 0), view(L, 0)); }
+    catch (e) { if (dev) L.free(); if (/near\) singular/.test(e.message)) throw new Error('Matrix contains NaNs or is (near) singular.'); throw e; }
+    finally { release(temps); }
+    return wrap(dev, S.shape, L);
+  };
+
+  la.cholesky_solve = function cholesky_solve(L, y) {      // cholesky.js:74-150
+    L = asarray(L); y = asarray(y);
+    if (L.ndim < 2) throw new Error('L must be at least 2D.');
+    if (y.ndim < 2) throw new Error('y must be at least 2D.');
+    const N = L.shape[L.ndim - 2], M = L.shape[L.ndim - 1], I = y.shape[y.ndim - 2], J = y.shape[y.ndim - 1];
+    if (N != M) throw new Error('Last two dimensions of L must be quadratic.');
+    if (I != M) throw new Error("L and y don't match.");
+    if (!gpuOk(L) || !gpuOk(y)) { if (fallback && fallback.cholesky_solve) return fallback.cholesky_solve(L, y); throw new Error('nd4hip.cholesky_solve: dtype is not accelerated.'); }
+    const lL = Array.from(L.shape.subarray(0, L.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
+    const lead = bcastLead([lL, lY], 'Shapes are not broadcast-compatible.');
+    const dev = isDev(L) || isDev(y), temps = [];
+    const X = alloc(dev, lead.reduce((a, b) => a * b, 1) * N * J), Ld = opF64(L, dev, temps), yd = opF64(y, dev, temps);
+    for (const [cnt, [oL, oY], [sL, sY], b0] of bcastGroupsN(lead, [lL, lY], [N * N, N * J]))
+      native().dpotrs_batched(cnt, N, J, view(Ld, oL), sL, view(yd, oY), sY, view(X, b0 * N * J));
+    release(temps);
+    return wrap(dev, [...lead, N, J], X);
+  };
+
   /* ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ---- */
   la.qr_lstsq = function qr_lstsq(Q, R, y) {
     if (undefined == y) { y = R; [Q, R] = Q; }
@@ -459,7 +491,8 @@ function install(nd) {
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp, qr_decomp_full: nd.la.qr_decomp_full,
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
-                    qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve};
+                    qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve,
+                    cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

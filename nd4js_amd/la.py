@@ -407,3 +407,45 @@ def svd_solve(U, sv, V=None, y=None, device=None):
     if np.asarray(U).shape[-2] != np.asarray(V).shape[-1]:
         raise ValueError("rrqr_solve(Q,R,P, y): System not square.")
     return svd_lstsq(U, sv, V, y, device=device)
+
+
+def cholesky_decomp(S, device=None):
+    """cholesky.js:51-71: L with S = L L^T, strict upper part zero; only the lower triangle of S is read."""
+    S = _asarray(S, "cholesky_decomp(S)")
+    if S.ndim < 2 or S.shape[-1] != S.shape[-2]:
+        raise ValueError("Last two dimensions must be quadratic.")
+    N = S.shape[-1]
+    L = np.empty_like(S)
+    h = _lib.handle(device)
+    try:
+        _lib.check(h.lib.nd4hip_dpotrf_batched(h.ptr, int(np.prod(S.shape[:-2], dtype=np.int64)), N, _ptr(S), _ptr(L)))
+    except _lib.Nd4HipError as e:
+        if e.code == -5:
+            raise ValueError("Matrix contains NaNs or is (near) singular.")      # cholesky.js:43-44
+        raise
+    return L
+
+
+def cholesky_solve(L, y, device=None):
+    """cholesky.js:74-150"""
+    L, y = np.asarray(L), np.asarray(y)
+    if L.ndim < 2:
+        raise ValueError("L must be at least 2D.")
+    if y.ndim < 2:
+        raise ValueError("y must be at least 2D.")
+    L, y = _asarray(L, "cholesky_solve"), _asarray(y, "cholesky_solve")
+    N, M = L.shape[-2:]
+    I, J = y.shape[-2:]
+    if N != M:
+        raise ValueError("Last two dimensions of L must be quadratic.")
+    if I != M:
+        raise ValueError("L and y don't match.")
+    try:
+        lead = np.broadcast_shapes(L.shape[:-2], y.shape[:-2])
+    except ValueError:
+        raise ValueError("Shapes are not broadcast-compatible.")
+    X = np.empty(tuple(lead) + (N, J))
+    h = _lib.handle(device)
+    for cnt, (oL, oY), (sL, sY), b0 in _bcast_groups_n(tuple(lead), [L.shape[:-2], y.shape[:-2]], [N * N, N * J]):
+        _lib.check(h.lib.nd4hip_dpotrs_batched(h.ptr, cnt, N, J, _off(L, oL), sL, _off(y, oY), sY, _off(X, b0 * N * J)))
+    return X

@@ -43,6 +43,9 @@ def lib():
         L.nd4o_tril_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_triu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
         L.nd4o_lu_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _ip, _i64, _dp, _i64, _dp]
+        L.nd4o_cholesky_decomp.argtypes = [_i64, _i64, _dp, _dp]
+        L.nd4o_cholesky_decomp.restype = ctypes.c_int
+        L.nd4o_cholesky_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_qr_decomp_inplace.argtypes = [_i64, _i64, _i64, _dp, _dp]
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
@@ -229,3 +232,38 @@ def qr_decomp_inplace(A, Y):
     for b in range(a2.shape[0]):
         lib().nd4o_qr_decomp_inplace(M, N, L, _d(a2[b]), _d(y2[b]))
     return A, Y
+
+
+def cholesky_decomp(S):
+    """cholesky.js:51-71"""
+    S = _f64(S)
+    N = S.shape[-1]
+    if S.ndim < 2 or S.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    L = np.empty_like(S)
+    if lib().nd4o_cholesky_decomp(int(np.prod(S.shape[:-2], dtype=np.int64)), N, _d(S), _d(L)):
+        raise ValueError("Matrix contains NaNs or is (near) singular.")
+    return L
+
+
+def cholesky_solve(L, Y):
+    """cholesky.js:74-150"""
+    L, Y = _f64(L), _f64(Y)
+    if L.ndim < 2:
+        raise ValueError("L must be at least 2D.")
+    if Y.ndim < 2:
+        raise ValueError("y must be at least 2D.")
+    N, J = Y.shape[-2:]
+    if L.shape[-1] != L.shape[-2]:
+        raise ValueError("Last two dimensions of L must be quadratic.")
+    if L.shape[-1] != N:
+        raise ValueError("L and y don't match.")
+    try:
+        lead = _bcast3([L.shape[:-2], Y.shape[:-2]])
+    except ValueError:
+        raise ValueError("Shapes are not broadcast-compatible.")
+    Lb = np.ascontiguousarray(np.broadcast_to(L, lead + (N, N)))
+    Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
+    X = np.empty(lead + (N, J))
+    lib().nd4o_cholesky_solve(int(np.prod(lead, dtype=np.int64)), N, J, _d(Lb), N * N, _d(Yb), N * J, _d(X))
+    return X

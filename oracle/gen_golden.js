@@ -257,6 +257,33 @@ if (what === 'inplace') {
   caseInplace('inplace_qr_100x37', 133, [100, 37], 134, 9);
 }
 
+if (what === 'chol') {
+  /* SURVEY §8f N4: cholesky_decomp / cholesky_solve (cholesky.js:51-150). SPD input S = B B^T + N I from the seeded B,
+     formed here with the reference's own matmul2 and committed only through the seed (the oracle's matmul2 is bit-identical). */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const spd = (seed, shape) => {
+    const N = shape[shape.length - 1], B = NDA(shape, fill(seed, numel(shape))), S = nd.la.matmul2(B, B.T);
+    for (let o = 0; o < S.data.length; o += N * N) for (let i = 0; i < N; i++) S.data[o + i * N + i] += N;
+    return S;
+  };
+  const caseChol = (name, seed, shape, seedY, shapeY) => {
+    const S = spd(seed, shape), L = nd.la.cholesky_decomp(S);
+    const t = {L: [L.data, Array.from(L.shape)]}, meta = {op: 'cholesky_decomp', seed, shape};
+    if (seedY !== undefined) {
+      const X = nd.la.cholesky_solve(L, NDA(shapeY, fill(seedY, numel(shapeY))));
+      t.X = [X.data, Array.from(X.shape)]; meta.seedY = seedY; meta.shapeY = shapeY;
+    }
+    record(name, meta, t);
+  };
+  caseChol('chol_1x1', 141, [1, 1], 142, [1, 3]);
+  caseChol('chol_32', 143, [32, 32], 144, [32, 5]);
+  caseChol('chol_33', 145, [33, 33], 146, [33, 1]);
+  caseChol('chol_batch', 147, [3, 2, 20, 20], 148, [2, 20, 4]);
+  caseChol('chol_bcast_y', 149, [40, 40], 150, [3, 40, 2]);
+  caseChol('chol_100', 151, [100, 100], 152, [100, 70]);
+  caseChol('chol_257', 153, [257, 257]);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

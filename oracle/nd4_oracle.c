@@ -229,6 +229,53 @@ void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_
   }
 }
 
+/* ------------------------------------------------------------------ Cholesky (cholesky.js) */
+/* src/la/cholesky.js:27-48 _cholesky_decomp with the Kahan accumulator of src/kahan_sum.js:22-46, preceded by the copy of
+ * the lower triangle into a zeroed L (:63-68). Returns -1 where the reference throws (NaN pivot :43-44, NaN input via
+ * KahanSum.set). */
+int nd4o_cholesky_decomp(int64_t batch, int64_t N, const double* S, double* L) {
+  for (int64_t b = 0; b < batch; b++) {
+    const double* s = S + b * N * N; double* l = L + b * N * N;
+    for (int64_t e = 0; e < N * N; e++) l[e] = 0.0;
+    for (int64_t i = 0; i < N; i++)
+      for (int64_t j = 0; j <= i; j++) l[N * i + j] = s[N * i + j];
+    for (int64_t i = 0; i < N; i++)
+      for (int64_t j = 0; j <= i; j++) {
+        double sum = l[N * i + j], rst = 0.0;                      /* kahan.set */
+        if (isnan(sum)) return -1;
+        for (int64_t k = 0; k < j; k++) {                          /* kahan.add(-L_ik L_jk) */
+          const double val = -l[N * i + k] * l[N * j + k];
+          const double cor = val - rst, t = sum + cor;
+          rst = (t - sum) - cor;
+          sum = t;
+        }
+        if (i > j) l[N * i + j] = sum / l[N * j + j];
+        else {
+          l[N * i + i] = sqrt(sum);
+          if (isnan(l[N * i + i])) return -1;
+        }
+      }
+  }
+  return 0;
+}
+
+static void tril_t_solve1(int64_t M, int64_t N, int64_t O, const double* L, double* X) {      /* tri.js:115-124 */
+  for (int64_t k = M; k-- > 0;) {
+    for (int64_t j = O; j-- > 0;) X[O * k + j] /= L[N * k + k];
+    for (int64_t i = k; i-- > 0;)
+      for (int64_t j = O; j-- > 0;) X[O * i + j] -= L[N * k + i] * X[O * k + j];
+  }
+}
+/* src/la/cholesky.js:74-150 cholesky_solve core (:117-123): copy y, _tril_solve, _tril_t_solve */
+void nd4o_cholesky_solve(int64_t batch, int64_t N, int64_t J, const double* L, int64_t sL, const double* Y, int64_t sY, double* X) {
+  for (int64_t b = 0; b < batch; b++) {
+    double* x = X + b * N * J; const double* y = Y + b * sY;
+    for (int64_t e = 0; e < N * J; e++) x[e] = y[e];
+    tril_solve1(N, N, J, L + b * sL, x);
+    tril_t_solve1(N, N, J, L + b * sL, x);
+  }
+}
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace: Givens elimination of A (M x N) in place, the same rotations applied to the
  * rows of Y (M x L). The bundle /root/reference/dist/nd.js does not export this function, so it is pinned through the
  * reference's own test oracle (qr_test.js:213-225): A == R and Y == Q^T Y of qr_decomp_full. */

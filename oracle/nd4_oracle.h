@@ -52,6 +52,12 @@ void nd4o_triu_solve(int64_t batch, int64_t M, int64_t O, const double* U, int64
 void nd4o_lu_solve(int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU, const int32_t* P, int64_t strideP,
                    const double* Y, int64_t strideY, double* X);
 
+/* src/la/cholesky.js:51-71 cholesky_decomp (kernel :27-48, Kahan sums): S [batch,N,N] (lower triangle read) -> L, upper
+ * part zero. Returns -1 where the reference throws. */
+int nd4o_cholesky_decomp(int64_t batch, int64_t N, const double* S, double* L);
+/* src/la/cholesky.js:74-150 cholesky_solve core: X = L^-T L^-1 Y (strides in doubles, 0 = broadcast) */
+void nd4o_cholesky_solve(int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL, const double* Y, int64_t strideY, double* X);
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace on one matrix: A [M,N] <- R, Y [M,L] <- Q^T Y */
 void nd4o_qr_decomp_inplace(int64_t M, int64_t N, int64_t L, double* A, double* Y);
 

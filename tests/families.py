@@ -52,3 +52,14 @@ def triangle(seed, shape, upper):
         t = (np.triu(a[b], 1) if upper else np.tril(a[b], -1)) * 0.25
         a[b] = t + np.diag(d)
     return a.reshape(shape)
+
+
+def spd(seed, shape):
+    """S = B B^T + N I from the seeded B (oracle/gen_golden.js `chol`): symmetric positive definite, cond ~ 2."""
+    import oracle
+    from nd4js_amd import rng
+    B = rng.matrix(seed, *shape)
+    N = shape[-1]
+    S = oracle.matmul2(B, np.swapaxes(B, -1, -2).copy())
+    S[..., np.arange(N), np.arange(N)] += N
+    return S

@@ -42,6 +42,8 @@ if (mode === 'cpu') {
   assert.throws(() => la.svd_lstsq(fill(1, [4, 3]), fill(2, [2]), fill(3, [3, 3]), fill(4, [4, 1])), /U and sv don't match/);
   assert.throws(() => la.svd_lstsq(fill(1, [2, 2]), new la.NDArray(Int32Array.of(2), Float64Array.of(1, NaN)), fill(3, [2, 2]), fill(4, [2, 1])), /NaN or Infinity/);
   assert.throws(() => la.svd_solve(fill(1, [4, 3]), fill(2, [3]), fill(3, [3, 3]), fill(4, [4, 1])), /System not square/);
+  assert.throws(() => la.cholesky_decomp(fill(1, [2, 3])), /must be quadratic/);
+  assert.throws(() => la.cholesky_solve(fill(1, [3, 3]), fill(2, [4, 1])), /L and y don't match/);
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
   assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
   assert.ok(/gfx950/.test(la.version()));
@@ -128,6 +130,12 @@ if (mode === 'gpu') {
     la._qr_decomp_inplace(20, 45, m.L, a, 0, y, 3);
     assert.ok(relerr(a, refR.data) <= 1e-12 && relerr(y.subarray(3), refY.data) <= 1e-11 && y[0] === 0 && y[2] === 0);
     assert.throws(() => la._qr_decomp_inplace(20, 45, m.L, a, 1, y, 3), /Assertion failed/); }
+  { const m = man.chol_bcast_y, N = m.shape[0], B = fill(m.seed, m.shape), S = la.matmul2(B, B.T);
+    for (let i = 0; i < N; i++) S.data[i * N + i] += N;
+    const L = la.cholesky_decomp(S), X = la.cholesky_solve(L, fill(m.seedY, m.shapeY)), refL = npy('chol_bcast_y', 'L'), refX = npy('chol_bcast_y', 'X');
+    assert.ok(relerr(L.data, refL.data) <= 1e-13); assert.deepStrictEqual(Array.from(X.shape), refX.shape); assert.ok(relerr(X.data, refX.data) <= 1e-12);
+    const dL = la.cholesky_decomp(la.to_device(S)); assert.ok(dL.onDevice); for (let i = 0; i < L.data.length; i++) assert.ok(L.data[i] === dL.data[i]);
+    assert.throws(() => la.cholesky_decomp([[1, 2], [2, 1]]), /Matrix contains NaNs or is \(near\) singular\./); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }

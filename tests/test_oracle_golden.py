@@ -176,3 +176,26 @@ def test_qr_decomp_inplace_matches_reference_test_oracle(golden, name):
     assert np.abs(qty - g["QtY"]).max() <= 1e-13 * max(np.abs(y).max(), 1) * M
     qf, rf = oracle.qr_decomp_full(a)                                     # and the oracle's own qr_decomp_full is the reference's
     assert np.array_equal(qf, g["Q"]) and np.array_equal(rf, g["R"])
+
+
+# ---- Cholesky (cholesky.js:27-150) ----
+from families import spd  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_cases(op="cholesky_decomp"))
+def test_cholesky_bit_exact(golden, name):
+    g = golden(name)
+    L = oracle.cholesky_decomp(spd(g.seed, tuple(g.shape)))
+    assert np.array_equal(L, g["L"])
+    if "X" in g.files:
+        x = oracle.cholesky_solve(L, rng.matrix(g.seedY, *g.shapeY))
+        assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+def test_cholesky_errors():
+    with pytest.raises(ValueError, match="near\\) singular"):
+        oracle.cholesky_decomp(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(ValueError, match="quadratic"):
+        oracle.cholesky_decomp(np.ones((2, 3)))
+    with pytest.raises(ValueError, match="L and y don't match"):
+        oracle.cholesky_solve(np.eye(3), np.ones((4, 1)))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Profiling driver: runs selected hot-path ops a few times so that
 `rocprofv3 --kernel-trace --stats -- python3 tools/prof_ops.py lu qr` gives per-kernel times.
-usage: prof_ops.py [matmul] [lu] [qr] [svd] [svdbatch] [--n N] [--reps R]"""
+usage: prof_ops.py [matmul] [lu] [qr] [chol] [svd] [svdbatch] [--n N] [--reps R]"""
 import os
 import sys
 
@@ -16,7 +16,12 @@ def main():
     n = int(args[args.index("--n") + 1]) if "--n" in args else 2048
     reps = int(args[args.index("--reps") + 1]) if "--reps" in args else 3
     A = dev.fill_uniform(7, (n, n))
+    if "chol" in args:
+        S = dev.gemm_ex(False, True, 1.0, A, A, 0.0, torch.empty_like(A), n, n, n, n, n, n)
+        S.diagonal().add_(float(n))
     for _ in range(reps):
+        if "chol" in args:
+            dev.cholesky_decomp(S)
         if "matmul" in args:
             dev.matmul2(A, A)
         if "lu" in args:
