@@ -116,6 +116,17 @@ int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_
 int nd4hip_dpotrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
                               const double* Y, int64_t strideY, double* X);
 
+/* ---- ldl_decomp / ldl_solve: replace src/la/ldl.js:67-90 (kernel :47-64) and :133-201 (kernel :93-130) ----
+ * S [batch,N,N] symmetric (lower triangle read), no pivoting -> packed LD [batch,N,N]: unit-lower L below the
+ * diagonal, D on it, exact zeros above; S = L D L^T. A zero pivot propagates Inf/NaN exactly like the reference
+ * (no check there either). dldltrs: X [batch,N,J] = L^-T D^-1 L^-1 Y; strides in elements, 0 = broadcast. */
+int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD);
+int nd4hip_dldltrf_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD);
+int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
+                               const double* Y, int64_t strideY, double* X);
+int nd4hip_dldltrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
+                               const double* Y, int64_t strideY, double* X);
+
 /* ---- qr_lstsq: replaces src/la/qr.js:186-273 -------------------------------------
  * X [batch,I,J] = R[0:L,0:L]^-1 (Q^T Y)[0:L,:], L = min(M,I), rows L..I-1 zero; Q [batch,N,M], R [batch,M,I]
  * (as returned by dgeqrf_q for an N x I system: M = min(N,I)), Y [batch,N,J]. I > N is refused like qr.js:209.

@@ -11,6 +11,9 @@
 //   chol_finish zero the strict upper triangle (the reference returns exact zeros there, cholesky.js:63-68).
 // Only the lower triangle of S is read (cholesky.js:65-67). A NaN pivot (negative or NaN radicand) raises the
 // per-matrix flag that the entry point turns into the reference's 'Matrix contains NaNs or is (near) singular.'
+//
+// LDL^T (src/la/ldl.js:47-201, no pivoting, D may be indefinite) shares the structure: ldl_diag / ldl_trsm keep the
+// UNSCALED panel W = L21 D11 next to L21 so that the trailing update is A22 -= W L21^T on the same tile-skipping GEMM.
 #include "nd4hip_internal.h"
 
 namespace {
@@ -102,6 +105,72 @@ __global__ __launch_bounds__(256) void chol_trsm(double* __restrict__ Lm, int N,
   }
 }
 
+// ---- LDL^T ----
+__global__ __launch_bounds__(64) void ldl_diag(double* __restrict__ Lm, int N, int j0, int nb) {
+  double* A = Lm + (long)blockIdx.x * N * N + (long)j0 * N + j0;
+  __shared__ double s_col[CB];
+  __shared__ double s_d;
+  const int i = threadIdx.x;
+  double a[CB];
+#pragma unroll
+  for (int k = 0; k < CB; k++) a[k] = (i < nb && k <= i && k < nb) ? A[(long)i * N + k] : 0.0;
+#pragma unroll
+  for (int j = 0; j < CB; j++) {
+    if (j < nb) {
+      if (i == j) s_d = a[j];                      // D_j (ldl.js:58-59 divides by LD[j,j])
+      if (i < CB) s_col[i] = a[j];                 // V = L[:,j] D_j, the unscaled column (ldl.js:52)
+      __syncthreads();
+      const double d = s_d;
+      if (i > j && i < nb) {
+        const double l = a[j] / d;
+#pragma unroll
+        for (int k = j + 1; k < CB; k++)
+          if (k <= i) a[k] -= l * s_col[k];
+        a[j] = l;
+      }
+      __syncthreads();
+    }
+  }
+  if (i < nb) {
+#pragma unroll
+    for (int k = 0; k < CB; k++)
+      if (k < nb) A[(long)i * N + k] = (k <= i) ? a[k] : 0.0;
+  }
+}
+
+// rows r in [j0+nb, N): y = A[r, j0:j0+nb] L11^-T (unit lower), W[r - r0, :] = y, L[r, j0:j0+nb] = y / D
+__global__ __launch_bounds__(256) void ldl_trsm(double* __restrict__ Lm, int N, int j0, int nb, double* __restrict__ Wm, long sW) {
+  double* Lb = Lm + (long)blockIdx.y * N * N;
+  double* W = Wm + (long)blockIdx.y * sW;
+  __shared__ double s_l[CB][CB + 1];
+  const int t = threadIdx.x;
+  for (int e = t; e < CB * CB; e += 256) {
+    const int i = e / CB, j = e % CB;
+    s_l[i][j] = (i < nb && j < nb && j <= i) ? Lb[(long)(j0 + i) * N + j0 + j] : (i == j ? 1.0 : 0.0);   // diagonal = D
+  }
+  __syncthreads();
+  const int r = j0 + nb + blockIdx.x * 256 + t;
+  if (r >= N) return;
+  double* row = Lb + (long)r * N + j0;
+  double* wrow = W + (long)(r - j0 - nb) * CB;
+  double x[CB];
+#pragma unroll
+  for (int k = 0; k < CB; k++) x[k] = (k < nb) ? row[k] : 0.0;
+#pragma unroll
+  for (int j = 0; j < CB; j++) {                   // y_j = a_j - sum_{k<j} y_k l_jk   (unit diagonal)
+    double s = x[j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= x[k] * s_l[j][k];
+    x[j] = s;
+    asm volatile("" : "+v"(x[j]) : "v"(&s_l[0][0]) : "memory");     // see chol_trsm
+  }
+#pragma unroll
+  for (int k = 0; k < CB; k++) {
+    wrow[k] = x[k];                                // columns >= nb are exact zeros: the K = 32 GEMM may read them
+    if (k < nb) row[k] = x[k] / s_l[k][k];
+  }
+}
+
 __global__ void chol_finish(double* __restrict__ Lm, int N) {
   const long base = (long)blockIdx.z * N * N;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,6 +203,54 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
   hipLaunchKernelGGL(chol_finish, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, L, N);
   ND4_HIP(hipGetLastError());
   return 0;
+}
+
+// S [batch, N, N] -> packed LD [batch, N, N] (ldl.js:67-90)
+int nd4_ldltrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, double* LD) {
+  ND4_CHECK_ARG(N64 < (1ll << 30) && batch64 < 65536, "nd4_ldltrf: extent out of range");
+  const int N = (int)N64, batch = (int)batch64;
+  if (N == 0 || batch == 0) return 0;
+  const long sL = (long)N * N, sW = (long)N * CB;
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (size_t)sW, &p));
+  double* W = static_cast<double*>(p);
+  const unsigned gy = (unsigned)(N < 1024 ? N : 1024);
+  hipLaunchKernelGGL(chol_copy_lower, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, S, LD, N);
+  for (int j0 = 0; j0 < N; j0 += CB) {
+    const int nb = N - j0 < CB ? N - j0 : CB;
+    hipLaunchKernelGGL(ldl_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, LD, N, j0, nb);
+    const int m2 = N - j0 - nb;
+    if (m2 <= 0) break;
+    hipLaunchKernelGGL(ldl_trsm, dim3((unsigned)((m2 + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, LD, N, j0, nb, W, sW);
+    ND4_HIP(hipGetLastError());
+    const int r0 = j0 + nb;                        // A22 -= (L21 D11) L21^T, tiles above the diagonal skipped
+    ND4_TRY(nd4_gemm_nt_lower(h, m2, nb, -1.0, W, CB, sW, LD + (long)r0 * N + j0, N, sL, 1.0, LD + (long)r0 * N + r0, N, sL, batch));
+  }
+  hipLaunchKernelGGL(chol_finish, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, LD, N);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
+// X[i, :] /= LD[i, i]   (ldl.js:120-122)
+__global__ void ldl_scale_rows(double* __restrict__ Xm, int N, int J, const double* __restrict__ LDm, long sLD) {
+  double* X = Xm + (long)blockIdx.z * N * J; const double* LD = LDm + blockIdx.z * sLD;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= J) return;
+  for (int i = blockIdx.y; i < N; i += gridDim.y) X[(long)i * J + col] /= LD[(long)i * N + i];
+}
+}  // namespace
+
+// X [batch, N, J] = L^-T D^-1 L^-1 Y (ldl.js:114-129); strides 0 = broadcast
+int nd4_ldltrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t sLD, const double* Y, int64_t sY, double* X) {
+  if (N == 0 || J == 0 || batch == 0) return 0;
+  if (X != Y || sY != N * J) ND4_TRY(nd4_copy_matrix(h, N, J, Y, J, X, J, batch, sY, N * J));
+  ND4_TRY(nd4_trsm_ld(h, false, true, batch, N, J, LD, N, sLD, X, N * J));         // forward, unit diagonal
+  const unsigned gy = (unsigned)(N < 1024 ? N : 1024);
+  hipLaunchKernelGGL(ldl_scale_rows, dim3((unsigned)((J + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, X, (int)N, (int)J, LD, (long)sLD);
+  ND4_HIP(hipGetLastError());
+  return nd4_trsm_t_ex(h, true, batch, N, J, LD, N, sLD, X, N * J);                // backward with L^T, unit diagonal
 }
 
 // X [batch, N, J] = L^-T L^-1 Y (cholesky.js:117-123); strides 0 = broadcast

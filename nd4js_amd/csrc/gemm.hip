@@ -250,14 +250,20 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
 // or lies below it is computed in full, tiles strictly above are skipped (their C entries are left untouched).
 int nd4_syrk_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int64_t sA,
                    double beta, double* C, int64_t ldc, int64_t sC, int64_t batch) {
+  return nd4_gemm_nt_lower(h, N, K, alpha, A, lda, sA, A, lda, sA, beta, C, ldc, sC, batch);
+}
+// the same with two different N x K factors: C[lower tiles] = alpha * A B^T + beta * C   (LDL^T: A = L21 D11, B = L21)
+int nd4_gemm_nt_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int64_t sA,
+                      const double* B, int64_t ldb, int64_t sB, double beta, double* C, int64_t ldc, int64_t sC, int64_t batch) {
   if (N <= 0 || batch <= 0) return 0;
-  ND4_CHECK_ARG(K >= 0 && N < (1 << 30) && K < (1 << 30), "nd4_syrk_lower: extent out of range");
-  ND4_CHECK_ARG(batch <= 65535, "nd4_syrk_lower: batch %lld exceeds 65535 per launch", (long long)batch);
+  ND4_CHECK_ARG(K >= 0 && N < (1 << 30) && K < (1 << 30), "nd4_gemm_nt_lower: extent out of range");
+  ND4_CHECK_ARG(batch <= 65535, "nd4_gemm_nt_lower: batch %lld exceeds 65535 per launch", (long long)batch);
   GemmArgs g;
-  g.A = A; g.B = A; g.C = C; g.M = (int)N; g.N = (int)N; g.K = (int)K;
-  g.lda = lda; g.ldb = lda; g.ldc = ldc; g.sA = sA; g.sB = sA; g.sC = sC;
+  g.A = A; g.B = B; g.C = C; g.M = (int)N; g.N = (int)N; g.K = (int)K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
   g.alpha = alpha; g.beta = beta; g.lower = 1;
   g.tiles_m = (int)((N + BM - 1) / BM); g.tiles_n = g.tiles_m;
-  const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (sA & 1) == 0 && (K & 1) == 0;
+  auto ok = [](const double* p, int64_t ld, int64_t st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0 && (st & 1) == 0; };
+  const bool vec = ok(A, lda, sA) && ok(B, ldb, sB) && (K & 1) == 0;
   return launch<false, true>(h, g, vec, batch);
 }

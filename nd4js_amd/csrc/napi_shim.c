@@ -51,6 +51,8 @@ static qrls_fn p_dqrls[2];
 static svdls_fn p_dsvdls[2];
 static getrs_fn p_dgetrs[2];
 static int (*p_dpotrf[2])(nd4hip_handle*, int64_t, int64_t, const double*, double*);
+static int (*p_dldltrf[2])(nd4hip_handle*, int64_t, int64_t, const double*, double*);
+static int (*p_dldltrs[2])(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
 static int (*p_dpotrs[2])(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
 static trsm_fn p_dtrsm[2];
 static int (*p_malloc)(nd4hip_handle*, size_t, void**);
@@ -97,6 +99,8 @@ static int load_library(void) {
   SYM2(p_dgetrs, "nd4hip_dgetrs_batched");
   SYM2(p_dpotrf, "nd4hip_dpotrf_batched");
   SYM2(p_dpotrs, "nd4hip_dpotrs_batched");
+  SYM2(p_dldltrf, "nd4hip_dldltrf_batched");
+  SYM2(p_dldltrs, "nd4hip_dldltrs_batched");
   SYM2(p_dqrls, "nd4hip_dqrls_batched");
   SYM2(p_dsvdls, "nd4hip_dsvdls_batched");
   SYM2(p_dtrsm, "nd4hip_dtrsm_batched");
@@ -386,6 +390,32 @@ static napi_value js_dpotrs(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* dldltrf_batched(batch, N, S, LD)   (ldl_decomp, ldl.js:67-90) */
+static napi_value js_dldltrf(napi_env env, napi_callback_info info) {
+  ARGS(4, "dldltrf_batched");
+  int64_t batch, N; opnd S, L;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || F64(2, S) || F64(3, L)) return NULL;
+  NEED(batch >= 0 && N >= 0 && (size_t)(batch * N * N) <= S.len && (size_t)(batch * N * N) <= L.len, "dldltrf_batched: buffer too small");
+  SAME_SIDE(S.dev == L.dev, "dldltrf_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dldltrf[S.dev](g_handle, batch, N, (const double*)S.p, (double*)L.p));
+  return NULL;
+}
+/* dldltrs_batched(batch, N, J, LD, strideLD, Y, strideY, X)   (ldl_solve, ldl.js:133-201) */
+static napi_value js_dldltrs(napi_env env, napi_callback_info info) {
+  ARGS(8, "dldltrs_batched");
+  int64_t batch, N, J, sL, sY; opnd L, Y, X;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || get_i64(env, a[2], &J) || F64(3, L) || get_i64(env, a[4], &sL) ||
+      F64(5, Y) || get_i64(env, a[6], &sY) || F64(7, X)) return NULL;
+  NEED(batch >= 0 && N >= 0 && J >= 0 && sL >= 0 && sY >= 0, "dldltrs_batched: negative extent");
+  NEED(batch == 0 || ((size_t)((batch - 1) * sL + N * N) <= L.len && (size_t)((batch - 1) * sY + N * J) <= Y.len && (size_t)(batch * N * J) <= X.len),
+       "dldltrs_batched: buffer too small");
+  SAME_SIDE(L.dev == Y.dev && Y.dev == X.dev, "dldltrs_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dldltrs[X.dev](g_handle, batch, N, J, (const double*)L.p, sL, (const double*)Y.p, sY, (double*)X.p));
+  return NULL;
+}
+
 /* ---- device memory ---- */
 /* dev_alloc(bytes) -> buffer */
 static napi_value js_dev_alloc(napi_env env, napi_callback_info info) {
@@ -473,6 +503,8 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dtrsm_batched", NULL, js_dtrsm, NULL, NULL, NULL, napi_default, NULL},
     {"dpotrf_batched", NULL, js_dpotrf, NULL, NULL, NULL, napi_default, NULL},
     {"dpotrs_batched", NULL, js_dpotrs, NULL, NULL, NULL, napi_default, NULL},
+    {"dldltrf_batched", NULL, js_dldltrf, NULL, NULL, NULL, napi_default, NULL},
+    {"dldltrs_batched", NULL, js_dldltrs, NULL, NULL, NULL, napi_default, NULL},
     {"dev_alloc", NULL, js_dev_alloc, NULL, NULL, NULL, napi_default, NULL},
     {"dev_free", NULL, js_dev_free, NULL, NULL, NULL, napi_default, NULL},
     {"dev_upload", NULL, js_dev_upload, NULL, NULL, NULL, napi_default, NULL},

@@ -306,6 +306,56 @@ extern "C" int nd4hip_dpotrs_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   return 0;
 }
 
+// ---- LDL^T: ldl_decomp (ldl.js:67-90), ldl_solve (:133-201)   
+extern "C" int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(S && LD, "nd4hip_dldltrf_batched: NULL pointer");
+  return nd4_ldltrf(h, batch, N, S, LD);
+}
+extern "C" int nd4hip_dldltrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)(batch * N * N);
+  DevBuf dS, dL;
+  ND4_TRY(dS.alloc(n * D)); ND4_TRY(dL.alloc(n * D));
+  ND4_TRY(h2d(h, dS.p, S, n * D));
+  ND4_TRY(nd4hip_dldltrf_batched_dev(h, batch, N, (const double*)dS.p, (double*)dL.p));
+  ND4_TRY(d2h(h, LD, dL.p, n * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
+                                          const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dldltrs_batched: negative extent");
+  ND4_CHECK_ARG((strideLD == 0 || strideLD >= N * N) && (strideY == 0 || strideY >= N * J),
+                "nd4hip_dldltrs_batched: a stride must be 0 or at least the size of one operand");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_CHECK_ARG(LD && Y && X, "nd4hip_dldltrs_batched: NULL pointer");
+  return nd4_ldltrs(h, batch, N, J, LD, strideLD, Y, strideY, X);
+}
+extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
+                                      const double* Y, int64_t strideY, double* X) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrs_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dldltrs_batched: negative extent");
+  if (batch == 0 || N == 0 || J == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t nL = (size_t)(strideLD ? (batch - 1) * strideLD + N * N : N * N);
+  const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
+  const size_t nX = (size_t)(batch * N * J);
+  DevBuf dL, dY, dX;
+  ND4_TRY(dL.alloc(nL * D)); ND4_TRY(dY.alloc(nY * D)); ND4_TRY(dX.alloc(nX * D));
+  ND4_TRY(h2d(h, dL.p, LD, nL * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
+  ND4_TRY(nd4hip_dldltrs_batched_dev(h, batch, N, J, (const double*)dL.p, strideLD, (const double*)dY.p, strideY, (double*)dX.p));
+  ND4_TRY(d2h(h, X, dX.p, nX * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ QR
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");

@@ -103,7 +103,11 @@ int nd4_trsm_ld(nd4hip_handle* h, bool upper, bool unit, int64_t batch, int64_t 
 }
 
 // in place: X <- L^-T X for a stored LOWER triangle L (non-unit diagonal): _tril_t_solve, tri.js:100-125
-int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M64, int64_t J64, const double* T, int64_t ldT64, int64_t sT, double* X, int64_t sX64) {
+int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M, int64_t J, const double* T, int64_t ldT, int64_t sT, double* X, int64_t sX) {
+  return nd4_trsm_t_ex(h, false, batch, M, J, T, ldT, sT, X, sX);
+}
+// unit = true: the diagonal of L is taken as ones (packed LD of ldl_decomp, ldl.js:125-129)
+int nd4_trsm_t_ex(nd4hip_handle* h, bool unit, int64_t batch, int64_t M64, int64_t J64, const double* T, int64_t ldT64, int64_t sT, double* X, int64_t sX64) {
   ND4_CHECK_ARG(M64 < (1ll << 30) && J64 < (1ll << 30) && batch < 65536, "nd4_trsm_t: extent out of range");
   const int M = (int)M64, J = (int)J64, ldT = (int)ldT64;
   if (M == 0 || J == 0 || batch == 0) return 0;
@@ -112,7 +116,7 @@ int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M64, int64_t J64, const 
   const int nblocks = (M + TB - 1) / TB;
   for (int b = nblocks - 1; b >= 0; b--) {
     const int r0 = b * TB, nbt = M - r0 < TB ? M - r0 : TB;
-    hipLaunchKernelGGL(tri_block_solve<true>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, 0, 1);
+    hipLaunchKernelGGL(tri_block_solve<true>, grid, dim3(256), 0, h->stream, T, ldT, (long)sT, X, J, sX, r0, nbt, unit ? 1 : 0, 1);
     ND4_HIP(hipGetLastError());
     if (r0 > 0)      // rows above: X[0:r0] -= L[block, 0:r0]^T X[block]
       ND4_TRY(nd4_gemm(h, true, false, r0, J, nbt, -1.0, T + (long)r0 * ldT, ldT, sT, X + (long)r0 * J, J, sX, 1.0, X, J, sX, batch));

@@ -245,3 +245,31 @@ def cholesky_solve(L, Y):
     b = _batch(lead)
     _lib.check(h.lib.nd4hip_dpotrs_batched_dev(h.ptr, b, N, J, _p(L), N * N if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
     return X
+
+
+def ldl_decomp(S):
+    _chk(S, "S")
+    N = S.shape[-1]
+    if S.dim() < 2 or S.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    LD = torch.empty_like(S)
+    h = _h(S)
+    _lib.check(h.lib.nd4hip_dldltrf_batched_dev(h.ptr, _batch(S.shape[:-2]), N, _p(S), _p(LD)))
+    return LD
+
+
+def ldl_solve(LD, Y):
+    _chk(LD, "LD"), _chk(Y, "Y")
+    N, J = Y.shape[-2:]
+    if LD.shape[-1] != LD.shape[-2]:
+        raise ValueError("ldl_solve(LD,y): Last two dimensions of LD must be quadratic.")
+    if LD.shape[-1] != N:
+        raise ValueError("ldl_solve(LD,y): LD and y don't match.")
+    lead = tuple(Y.shape[:-2])
+    if tuple(LD.shape[:-2]) != lead:
+        raise ValueError("Shapes are not broadcast-compatible.")       # general broadcasting: host wrapper (la.py)
+    X = torch.empty_like(Y)
+    h = _h(Y)
+    b = _batch(lead)
+    _lib.check(h.lib.nd4hip_dldltrs_batched_dev(h.ptr, b, N, J, _p(LD), N * N if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
+    return X

@@ -415,6 +415,36 @@ function makeLa(NDA, fallback) {
     return wrap(dev, [...lead, N, J], X);
   };
 
+  la.ldl_decomp = function ldl_decomp(S) {                 // ldl.js:67-90
+    S = asarray(S);
+    const nd_ = S.ndim;
+    if (nd_ < 2 || S.shape[nd_ - 2] !== S.shape[nd_ - 1]) throw new Error('Last two dimensions must be quadratic.');
+    if (!gpuOk(S)) { if (fallback && fallback.ldl_decomp) return fallback.ldl_decomp(S); throw new Error('nd4hip.ldl_decomp: dtype ' + dtypeOf(S) + ' is not accelerated.'); }
+    const N = S.shape[nd_ - 1], batch = prod(S.shape, 0, nd_ - 2), dev = isDev(S), temps = [];
+    const LD = alloc(dev, batch * N * N);
+    native().dldltrf_batched(batch, N, view(opF64(S, dev, temps), 0), view(LD, 0));
+    release(temps);
+    return wrap(dev, S.shape, LD);
+  };
+
+  la.ldl_solve = function ldl_solve(LD, y) {               // ldl.js:133-201
+    LD = asarray(LD); y = asarray(y);
+    if (LD.ndim < 2) throw new Error('ldl_solve(LD,y): LD must be at least 2D.');
+    if (y.ndim < 2) throw new Error('ldl_solve(LD,y): y must be at least 2D.');
+    const N = LD.shape[LD.ndim - 2], M = LD.shape[LD.ndim - 1], I = y.shape[y.ndim - 2], J = y.shape[y.ndim - 1];
+    if (N != M) throw new Error('ldl_solve(LD,y): Last two dimensions of LD must be quadratic.');
+    if (I != M) throw new Error("ldl_solve(LD,y): LD and y don't match.");
+    if (!gpuOk(LD) || !gpuOk(y)) { if (fallback && fallback.ldl_solve) return fallback.ldl_solve(LD, y); throw new Error('nd4hip.ldl_solve: dtype is not accelerated.'); }
+    const lL = Array.from(LD.shape.subarray(0, LD.ndim - 2)), lY = Array.from(y.shape.subarray(0, y.ndim - 2));
+    const lead = bcastLead([lL, lY], 'Shapes are not broadcast-compatible.');
+    const dev = isDev(LD) || isDev(y), temps = [];
+    const X = alloc(dev, lead.reduce((a, b) => a * b, 1) * N * J), Ld = opF64(LD, dev, temps), yd = opF64(y, dev, temps);
+    for (const [cnt, [oL, oY], [sL, sY], b0] of bcastGroupsN(lead, [lL, lY], [N * N, N * J]))
+      native().dldltrs_batched(cnt, N, J, view(Ld, oL), sL, view(yd, oY), sY, view(X, b0 * N * J));
+    release(temps);
+    return wrap(dev, [...lead, N, J], X);
+  };
+
   /* ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ---- */
   la.qr_lstsq = function qr_lstsq(Q, R, y) {
     if (undefined == y) { y = R; [Q, R] = Q; }
@@ -492,7 +522,8 @@ function install(nd) {
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
                     qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve,
-                    cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve};
+                    cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve,
+                    ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

@@ -449,3 +449,39 @@ def cholesky_solve(L, y, device=None):
     for cnt, (oL, oY), (sL, sY), b0 in _bcast_groups_n(tuple(lead), [L.shape[:-2], y.shape[:-2]], [N * N, N * J]):
         _lib.check(h.lib.nd4hip_dpotrs_batched(h.ptr, cnt, N, J, _off(L, oL), sL, _off(y, oY), sY, _off(X, b0 * N * J)))
     return X
+
+
+def ldl_decomp(S, device=None):
+    """ldl.js:67-90: packed LD (unit-lower L below the diagonal, D on it, zeros above), S = L D L^T, no pivoting."""
+    S = _asarray(S, "ldl_decomp(S)")
+    if S.ndim < 2 or S.shape[-1] != S.shape[-2]:
+        raise ValueError("Last two dimensions must be quadratic.")
+    LD = np.empty_like(S)
+    h = _lib.handle(device)
+    _lib.check(h.lib.nd4hip_dldltrf_batched(h.ptr, int(np.prod(S.shape[:-2], dtype=np.int64)), S.shape[-1], _ptr(S), _ptr(LD)))
+    return LD
+
+
+def ldl_solve(LD, y, device=None):
+    """ldl.js:133-201"""
+    LD, y = np.asarray(LD), np.asarray(y)
+    if LD.ndim < 2:
+        raise ValueError("ldl_solve(LD,y): LD must be at least 2D.")
+    if y.ndim < 2:
+        raise ValueError("ldl_solve(LD,y): y must be at least 2D.")
+    LD, y = _asarray(LD, "ldl_solve"), _asarray(y, "ldl_solve")
+    N, M = LD.shape[-2:]
+    I, J = y.shape[-2:]
+    if N != M:
+        raise ValueError("ldl_solve(LD,y): Last two dimensions of LD must be quadratic.")
+    if I != M:
+        raise ValueError("ldl_solve(LD,y): LD and y don't match.")
+    try:
+        lead = np.broadcast_shapes(LD.shape[:-2], y.shape[:-2])
+    except ValueError:
+        raise ValueError("Shapes are not broadcast-compatible.")
+    X = np.empty(tuple(lead) + (N, J))
+    h = _lib.handle(device)
+    for cnt, (oL, oY), (sL, sY), b0 in _bcast_groups_n(tuple(lead), [LD.shape[:-2], y.shape[:-2]], [N * N, N * J]):
+        _lib.check(h.lib.nd4hip_dldltrs_batched(h.ptr, cnt, N, J, _off(LD, oL), sL, _off(y, oY), sY, _off(X, b0 * N * J)))
+    return X

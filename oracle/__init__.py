@@ -46,6 +46,8 @@ def lib():
         L.nd4o_cholesky_decomp.argtypes = [_i64, _i64, _dp, _dp]
         L.nd4o_cholesky_decomp.restype = ctypes.c_int
         L.nd4o_cholesky_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
+        L.nd4o_ldl_decomp.argtypes = [_i64, _i64, _dp, _dp]
+        L.nd4o_ldl_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_qr_decomp_inplace.argtypes = [_i64, _i64, _i64, _dp, _dp]
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
@@ -266,4 +268,38 @@ def cholesky_solve(L, Y):
     Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
     X = np.empty(lead + (N, J))
     lib().nd4o_cholesky_solve(int(np.prod(lead, dtype=np.int64)), N, J, _d(Lb), N * N, _d(Yb), N * J, _d(X))
+    return X
+
+
+def ldl_decomp(S):
+    """ldl.js:67-90"""
+    S = _f64(S)
+    N = S.shape[-1]
+    if S.ndim < 2 or S.shape[-2] != N:
+        raise ValueError("Last two dimensions must be quadratic.")
+    LD = np.empty_like(S)
+    lib().nd4o_ldl_decomp(int(np.prod(S.shape[:-2], dtype=np.int64)), N, _d(S), _d(LD))
+    return LD
+
+
+def ldl_solve(LD, Y):
+    """ldl.js:133-201"""
+    LD, Y = _f64(LD), _f64(Y)
+    if LD.ndim < 2:
+        raise ValueError("ldl_solve(LD,y): LD must be at least 2D.")
+    if Y.ndim < 2:
+        raise ValueError("ldl_solve(LD,y): y must be at least 2D.")
+    N, J = Y.shape[-2:]
+    if LD.shape[-1] != LD.shape[-2]:
+        raise ValueError("ldl_solve(LD,y): Last two dimensions of LD must be quadratic.")
+    if LD.shape[-1] != N:
+        raise ValueError("ldl_solve(LD,y): LD and y don't match.")
+    try:
+        lead = _bcast3([LD.shape[:-2], Y.shape[:-2]])
+    except ValueError:
+        raise ValueError("Shapes are not broadcast-compatible.")
+    Lb = np.ascontiguousarray(np.broadcast_to(LD, lead + (N, N)))
+    Yb = np.ascontiguousarray(np.broadcast_to(Y, lead + (N, J)))
+    X = np.empty(lead + (N, J))
+    lib().nd4o_ldl_solve(int(np.prod(lead, dtype=np.int64)), N, J, _d(Lb), N * N, _d(Yb), N * J, _d(X))
     return X

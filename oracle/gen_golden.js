@@ -284,6 +284,38 @@ if (what === 'chol') {
   caseChol('chol_257', 153, [257, 257]);
 }
 
+if (what === 'ldl') {
+  /* SURVEY §8f N4: ldl_decomp / ldl_solve (ldl.js:47-201). Symmetric INDEFINITE input with safe pivots, built like the
+     reference's own test (ldl_test.js:44-50): S = L D L^T from a seeded unit-lower L (entries / 4) and D_i = +-(1 + |u|). */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const sym = (seed, shape) => {
+    const N = shape[shape.length - 1], r = fill(seed, numel(shape)), Ld = new Float64Array(r.length), Dd = new Float64Array(r.length);
+    for (let o = 0; o < r.length; o += N * N)
+      for (let i = 0; i < N; i++) for (let j = 0; j < N; j++) {
+        const k = o + i * N + j;
+        Ld[k] = i === j ? 1 : j < i ? r[k] * 0.25 : 0;
+        Dd[k] = i === j ? (r[k] >= 0 ? 1 + r[k] : -1 + r[k]) : 0;
+      }
+    const L = NDA(shape, Ld);
+    return nd.la.matmul2(nd.la.matmul2(L, NDA(shape, Dd)), L.T);
+  };
+  const caseLdl = (name, seed, shape, seedY, shapeY) => {
+    const LD = nd.la.ldl_decomp(sym(seed, shape)), t = {LD: [LD.data, Array.from(LD.shape)]}, meta = {op: 'ldl_decomp', seed, shape};
+    if (seedY !== undefined) {
+      const X = nd.la.ldl_solve(LD, NDA(shapeY, fill(seedY, numel(shapeY))));
+      t.X = [X.data, Array.from(X.shape)]; meta.seedY = seedY; meta.shapeY = shapeY;
+    }
+    record(name, meta, t);
+  };
+  caseLdl('ldl_1x1', 161, [1, 1], 162, [1, 2]);
+  caseLdl('ldl_32', 163, [32, 32], 164, [32, 5]);
+  caseLdl('ldl_33', 165, [33, 33], 166, [33, 1]);
+  caseLdl('ldl_batch', 167, [2, 3, 20, 20], 168, [3, 20, 4]);
+  caseLdl('ldl_bcast_y', 169, [40, 40], 170, [2, 40, 3]);
+  caseLdl('ldl_100', 171, [100, 100], 172, [100, 70]);
+  caseLdl('ldl_200', 173, [200, 200]);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

@@ -276,6 +276,40 @@ void nd4o_cholesky_solve(int64_t batch, int64_t N, int64_t J, const double* L, i
   }
 }
 
+/* ------------------------------------------------------------------ LDL^T (ldl.js) */
+/* src/la/ldl.js:47-64 _ldl_decomp after the lower-triangle copy of ldl_decomp (:82-87): packed LD, unit-L below the
+ * diagonal, D on it, zeros above. No pivoting, no singularity check (a zero pivot propagates Inf/NaN like the reference). */
+void nd4o_ldl_decomp(int64_t batch, int64_t N, const double* S, double* LD) {
+  for (int64_t b = 0; b < batch; b++) {
+    const double* s = S + b * N * N; double* ld = LD + b * N * N;
+    for (int64_t e = 0; e < N * N; e++) ld[e] = 0.0;
+    for (int64_t i = 0; i < N; i++)
+      for (int64_t j = 0; j <= i; j++) ld[N * i + j] = s[N * i + j];
+    for (int64_t j = 0; j < N; j++) {
+      for (int64_t k = 0; k < j; k++) {
+        const double V_k = ld[N * j + k] * ld[N * k + k];
+        for (int64_t i = j; i < N; i++) ld[N * i + j] -= ld[N * i + k] * V_k;
+      }
+      for (int64_t i = j; ++i < N;) ld[N * i + j] /= ld[N * j + j];
+    }
+  }
+}
+/* src/la/ldl.js:93-130 _ldl_solve behind ldl_solve (:133-201): forward (unit L), scaling by D, backward (L^T) */
+void nd4o_ldl_solve(int64_t batch, int64_t N, int64_t J, const double* LD, int64_t sLD, const double* Y, int64_t sY, double* X) {
+  for (int64_t b = 0; b < batch; b++) {
+    const double* ld = LD + b * sLD; const double* y = Y + b * sY; double* x = X + b * N * J;
+    for (int64_t e = 0; e < N * J; e++) x[e] = y[e];
+    for (int64_t i = 1; i < N; i++)
+      for (int64_t k = 0; k < i; k++)
+        for (int64_t j = 0; j < J; j++) x[J * i + j] -= ld[N * i + k] * x[J * k + j];
+    for (int64_t i = 0; i < N; i++)
+      for (int64_t j = 0; j < J; j++) x[J * i + j] /= ld[N * i + i];
+    for (int64_t k = N; k-- > 1;)
+      for (int64_t i = k; i-- > 0;)
+        for (int64_t j = J; j-- > 0;) x[J * i + j] -= ld[N * k + i] * x[J * k + j];
+  }
+}
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace: Givens elimination of A (M x N) in place, the same rotations applied to the
  * rows of Y (M x L). The bundle /root/reference/dist/nd.js does not export this function, so it is pinned through the
  * reference's own test oracle (qr_test.js:213-225): A == R and Y == Q^T Y of qr_decomp_full. */

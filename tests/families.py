@@ -63,3 +63,18 @@ def spd(seed, shape):
     S = oracle.matmul2(B, np.swapaxes(B, -1, -2).copy())
     S[..., np.arange(N), np.arange(N)] += N
     return S
+
+
+def sym_indefinite(seed, shape):
+    """S = L D L^T from a seeded unit-lower L (entries / 4) and D_i = +-(1 + |u|) (oracle/gen_golden.js `ldl`)."""
+    import oracle
+    from nd4js_amd import rng
+    r = rng.matrix(seed, *shape)
+    N = shape[-1]
+    idx = np.arange(N)
+    L = np.tril(r * 0.25, -1)
+    L[..., idx, idx] = 1.0
+    D = np.zeros_like(r)
+    d = r[..., idx, idx]
+    D[..., idx, idx] = np.where(d >= 0, 1 + d, -1 + d)
+    return oracle.matmul2(oracle.matmul2(L, D), np.swapaxes(L, -1, -2).copy())

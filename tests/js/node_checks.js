@@ -43,6 +43,7 @@ if (mode === 'cpu') {
   assert.throws(() => la.svd_lstsq(fill(1, [2, 2]), new la.NDArray(Int32Array.of(2), Float64Array.of(1, NaN)), fill(3, [2, 2]), fill(4, [2, 1])), /NaN or Infinity/);
   assert.throws(() => la.svd_solve(fill(1, [4, 3]), fill(2, [3]), fill(3, [3, 3]), fill(4, [4, 1])), /System not square/);
   assert.throws(() => la.cholesky_decomp(fill(1, [2, 3])), /must be quadratic/);
+  assert.throws(() => la.ldl_solve(fill(1, [3, 3]), fill(2, [4, 1])), /ldl_solve\(LD,y\): LD and y don't match/);
   assert.throws(() => la.cholesky_solve(fill(1, [3, 3]), fill(2, [4, 1])), /L and y don't match/);
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
   assert.deepStrictEqual(g.map(x => x.slice(0, 5)), [[4, 0, 0, 0, 42], [4, 35, 0, 0, 42], [4, 70, 0, 0, 42]]);
@@ -136,6 +137,13 @@ if (mode === 'gpu') {
     assert.ok(relerr(L.data, refL.data) <= 1e-13); assert.deepStrictEqual(Array.from(X.shape), refX.shape); assert.ok(relerr(X.data, refX.data) <= 1e-12);
     const dL = la.cholesky_decomp(la.to_device(S)); assert.ok(dL.onDevice); for (let i = 0; i < L.data.length; i++) assert.ok(L.data[i] === dL.data[i]);
     assert.throws(() => la.cholesky_decomp([[1, 2], [2, 1]]), /Matrix contains NaNs or is \(near\) singular\./); }
+  { const m = man.ldl_bcast_y, refLD = npy('ldl_bcast_y', 'LD'), refX = npy('ldl_bcast_y', 'X'), N = m.shape[0];
+    const L = new la.NDArray(Int32Array.of(N, N), Float64Array.from(refLD.data, (v, k) => (k % N === (k / N | 0)) ? 1 : v));
+    const Dm = new la.NDArray(Int32Array.of(N, N), Float64Array.from(refLD.data, (v, k) => (k % N === (k / N | 0)) ? v : 0));
+    const S = la.matmul(L, Dm, L.T), LD = la.ldl_decomp(S);                   // S rebuilt from the reference's factors
+    assert.ok(relerr(LD.data, refLD.data) <= 1e-12);
+    const X = la.ldl_solve(new la.NDArray(Int32Array.of(N, N), refLD.data), fill(m.seedY, m.shapeY));
+    assert.deepStrictEqual(Array.from(X.shape), refX.shape); assert.ok(relerr(X.data, refX.data) <= 1e-12); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }

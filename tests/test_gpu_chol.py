@@ -106,3 +106,82 @@ def test_cholesky_device_resident_chain(la):
     bad = S.copy(); bad[2, 0, 0] = -4.0
     with pytest.raises(ValueError, match="near\\) singular"):
         dev.cholesky_decomp(torch.from_numpy(bad).cuda())
+
+
+# ---- LDL^T (ldl.js:47-201): no pivoting, indefinite D ----
+from families import sym_indefinite  # noqa: E402
+
+
+def _unpack(LD):
+    N = LD.shape[-1]
+    idx = np.arange(N)
+    L = np.tril(LD, -1)
+    L[..., idx, idx] = 1.0
+    return L, LD[..., idx, idx]
+
+
+@pytest.mark.parametrize("name", golden_cases(op="ldl_decomp"))
+def test_ldl_golden(la, golden, name):
+    g = golden(name)
+    S = sym_indefinite(g.seed, tuple(g.shape))
+    LD = la.ldl_decomp(S)
+    ref = g["LD"]
+    assert LD.shape == ref.shape
+    assert np.array_equal(np.triu(LD, 1), np.zeros_like(LD))
+    assert relerr(LD, ref) <= 1e-13
+    assert np.array_equal(np.sign(_unpack(LD)[1]), np.sign(_unpack(ref)[1]))     # inertia: indefinite on purpose
+    if "X" in g.files:
+        y = rng.matrix(g.seedY, *g.shapeY)
+        x = la.ldl_solve(LD, y)
+        assert x.shape == g["X"].shape and relerr(x, g["X"]) <= 1e-12
+        assert relerr(la.ldl_solve(ref, y), g["X"]) <= 1e-13
+
+
+@pytest.mark.parametrize("N", [1, 2, 31, 32, 33, 64, 100, 257, 512, 1024, 2048])
+def test_ldl_sizes(la, N):
+    r = rng.matrix(5700 + N, N, N)
+    L0 = np.tril(r * (0.25 if N <= 512 else 2.0 / N), -1) + np.eye(N)
+    d0 = np.where(np.diag(r) >= 0, 1 + np.diag(r), -1 + np.diag(r))
+    S = (L0 * d0) @ L0.T
+    LD = la.ldl_decomp(S)
+    L, d = _unpack(LD)
+    assert np.array_equal(np.triu(LD, 1), np.zeros_like(LD))
+    assert np.linalg.norm((L * d) @ L.T - S) <= 64 * EPS * N * np.linalg.norm(S)
+    assert np.abs(L - L0).max() <= 1e-9 and np.abs(d - d0).max() <= 1e-9          # ldl_test.js: decomp(L D L^T) == (L, D)
+    if N <= 512:                                   # two valid roundings of an unpivoted factorisation differ by ~eps * cond
+        assert relerr(LD, oracle.ldl_decomp(S)) <= 4 * EPS * max(np.linalg.cond(S), 100)
+
+
+def test_ldl_reads_only_the_lower_triangle(la):
+    S = sym_indefinite(5800, (48, 48))
+    junk = S + np.triu(rng.matrix(5801, 48, 48), 1) * 1e6
+    assert np.array_equal(la.ldl_decomp(junk), la.ldl_decomp(S))
+
+
+@pytest.mark.parametrize("N,J", [(1, 1), (33, 5), (100, 257), (512, 64), (1100, 3)])
+def test_ldl_solve_vs_oracle(la, N, J):
+    S = sym_indefinite(5900 + N, (N, N)) if N <= 512 else None
+    if S is None:
+        r = rng.matrix(5900 + N, N, N)
+        L0 = np.tril(r * 2.0 / N, -1) + np.eye(N)
+        S = (L0 * np.where(np.diag(r) >= 0, 1 + np.diag(r), -1 + np.diag(r))) @ L0.T
+    y = rng.matrix(6000 + J, N, J)
+    LD = oracle.ldl_decomp(S)
+    x = la.ldl_solve(LD, y)
+    assert relerr(x, oracle.ldl_solve(LD, y)) <= 1e-13
+    assert np.abs(S @ x - y).max() <= 1e-10 * N
+
+
+def test_ldl_errors_and_device_chain(la):
+    import torch
+    from nd4js_amd import dev
+    with pytest.raises(ValueError, match="quadratic"):
+        la.ldl_decomp(np.ones((2, 3)))
+    with pytest.raises(ValueError, match="LD and y don't match"):
+        la.ldl_solve(np.eye(3), np.ones((4, 1)))
+    S = sym_indefinite(6100, (3, 80, 80))
+    y = rng.matrix(6101, 3, 80, 5)
+    LDd = dev.ldl_decomp(torch.from_numpy(S).cuda())
+    xd = dev.ldl_solve(LDd, torch.from_numpy(y).cuda())
+    assert np.array_equal(LDd.cpu().numpy(), la.ldl_decomp(S))
+    assert relerr(xd.cpu().numpy(), np.linalg.solve(S, y)) <= 1e-11

@@ -199,3 +199,17 @@ def test_cholesky_errors():
         oracle.cholesky_decomp(np.ones((2, 3)))
     with pytest.raises(ValueError, match="L and y don't match"):
         oracle.cholesky_solve(np.eye(3), np.ones((4, 1)))
+
+
+# ---- LDL^T (ldl.js:47-201) ----
+from families import sym_indefinite  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_cases(op="ldl_decomp"))
+def test_ldl_bit_exact(golden, name):
+    g = golden(name)
+    LD = oracle.ldl_decomp(sym_indefinite(g.seed, tuple(g.shape)))
+    assert np.array_equal(LD, g["LD"])
+    if "X" in g.files:
+        x = oracle.ldl_solve(LD, rng.matrix(g.seedY, *g.shapeY))
+        assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
