@@ -23,6 +23,7 @@
 //    the 16-byte vector path needs even leading dimensions / extents / offsets, otherwise the
 //    scalar path (8-byte loads) runs.
 #include "nd4hip_internal.h"
+#include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -210,6 +211,109 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- rank-k update kernel: K <= 32, A not transposed --------------------------------------------------------------
+// The trailing updates of LU / QR / Cholesky / LDL and of the blocked triangular solves are C (+)= alpha A op(B) with
+// K = 16 or 32: two K-steps of the tiled kernel above, whose fixed cost (LDS staging, barriers, one workgroup per CU
+// at 2048^2) is then most of the launch. Here nothing is staged: every wave owns 32 x 64 of C (2 x 4 accumulators),
+// reads its A rows and the B panel straight from global memory in MFMA operand layout (cache-line-complete, the four
+// waves of a workgroup share the B panel through L1/L2), starts the accumulators at (beta/alpha) C (exact for the
+// alpha = +-1, beta in {0, +-1} these callers use; other combinations take the tiled kernel), and writes alpha * acc.
+// No LDS, no barrier, 2 workgroups of 128 x 64 per CU: the launch is bound by the read-modify-write of C.
+constexpr int SK_RT = 1;                                   // 16-row MFMA tiles per wave
+constexpr int SK_CT = 2;                                   // 16-column MFMA tiles per wave
+constexpr int SK_BM = 4 * 16 * SK_RT, SK_BN = 16 * SK_CT, SK_KSTEPS = 8;
+
+template <bool TB>
+__global__ __launch_bounds__(256, 4) void dgemm_smallk_kernel(GemmArgs g) {
+  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x % g.tiles_n;
+  const int m0 = tm * SK_BM, n0 = tn * SK_BN;
+  if (g.lower && n0 > m0 + SK_BM - 1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fx = lane & 15, fk = lane >> 4;
+  const int rbase = m0 + w * 16 * SK_RT;
+  if (rbase >= g.M) return;                                  // no barrier anywhere: a wave may leave alone
+  const long bz = blockIdx.y;
+  const double* __restrict__ A = g.A + bz * g.sA;
+  const double* __restrict__ B = g.B + bz * g.sB;
+  double* __restrict__ C = g.C + bz * g.sC;
+  const int nk = (g.K + 3) >> 2;
+
+  d4 acc[SK_RT][SK_CT];
+  const double scale = (g.beta == 0.0) ? 0.0 : g.beta / g.alpha;
+#pragma unroll
+  for (int i = 0; i < SK_RT; i++)
+#pragma unroll
+    for (int j = 0; j < SK_CT; j++) {
+      const int col = n0 + j * 16 + fx;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = rbase + i * 16 + fk + 4 * r;
+        double c = 0.0;
+        if (scale != 0.0 && row < g.M && col < g.N) c = scale * C[(long)row * g.ldc + col];
+        acc[i][j][r] = c;
+      }
+    }
+  double a[SK_RT][SK_KSTEPS], b[SK_CT][SK_KSTEPS];
+#pragma unroll
+  for (int i = 0; i < SK_RT; i++) {
+    const int row = rbase + i * 16 + fx;
+    const double* ap = A + (long)row * g.lda + fk;
+#pragma unroll
+    for (int kk = 0; kk < SK_KSTEPS; kk++) a[i][kk] = (row < g.M && kk * 4 + fk < g.K) ? ap[kk * 4] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < SK_CT; j++) {
+    const int col = n0 + j * 16 + fx;
+#pragma unroll
+    for (int kk = 0; kk < SK_KSTEPS; kk++) {
+      const int k = kk * 4 + fk;
+      double v = 0.0;
+      if (col < g.N && k < g.K) v = TB ? B[(long)col * g.ldb + k] : B[(long)k * g.ldb + col];
+      b[j][kk] = v;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < SK_KSTEPS; kk++)
+    if (kk < nk) {
+#pragma unroll
+      for (int i = 0; i < SK_RT; i++)
+#pragma unroll
+        for (int j = 0; j < SK_CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+    }
+  const double alpha = g.alpha;
+#pragma unroll
+  for (int i = 0; i < SK_RT; i++)
+#pragma unroll
+    for (int j = 0; j < SK_CT; j++) {
+      const int col = n0 + j * 16 + fx;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = rbase + i * 16 + fk + 4 * r;
+        if (row < g.M && col < g.N) C[(long)row * g.ldc + col] = alpha * acc[i][j][r];
+      }
+    }
+}
+
+// the callers' (alpha, beta) for which starting the accumulators at (beta/alpha) C is exact
+bool smallk_ok(const GemmArgs& g, bool transA) {
+  return !transA && g.K >= 1 && g.K <= 4 * SK_KSTEPS && (g.alpha == 1.0 || g.alpha == -1.0) &&
+         (g.beta == 0.0 || g.beta == 1.0 || g.beta == -1.0);
+}
+template <bool TB>
+int launch_smallk(nd4hip_handle* h, GemmArgs g, int64_t batch) {
+  g.tiles_m = (g.M + SK_BM - 1) / SK_BM; g.tiles_n = (g.N + SK_BN - 1) / SK_BN;
+  ND4_CHECK_ARG((int64_t)g.tiles_m * g.tiles_n < (1ll << 31), "nd4_gemm: too many tiles");
+  hipLaunchKernelGGL((dgemm_smallk_kernel<TB>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1), dim3(256, 1, 1), 0, h->stream, g);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+// ND4HIP_GEMM_TILED=1 sends every product through the tiled kernel (A/B measurements of the rank-k kernel)
+bool nd4_gemm_force_tiled() {
+  static const bool v = [] { const char* e = getenv("ND4HIP_GEMM_TILED"); return e && *e && *e != '0'; }();
+  return v;
+}
+
 template <bool TA, bool TB>
 int launch(nd4hip_handle* h, const GemmArgs& g, bool vec, int64_t batch) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1), block(256, 1, 1);
@@ -236,6 +340,7 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
   g.alpha = alpha; g.beta = beta; g.lower = 0;
   g.tiles_m = (int)((M + BM - 1) / BM); g.tiles_n = (int)((N + BN - 1) / BN);
   ND4_CHECK_ARG((int64_t)g.tiles_m * g.tiles_n < (1ll << 31), "nd4_gemm: too many tiles");
+  if (smallk_ok(g, transA) && !nd4_gemm_force_tiled()) return transB ? launch_smallk<true>(h, g, batch) : launch_smallk<false>(h, g, batch);
   auto even = [](int64_t v) { return (v & 1) == 0; };
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // 16-byte loads need: aligned bases, even row strides / batch strides, and an even extent along
@@ -262,6 +367,7 @@ int nd4_gemm_nt_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, cons
   g.A = A; g.B = B; g.C = C; g.M = (int)N; g.N = (int)N; g.K = (int)K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
   g.alpha = alpha; g.beta = beta; g.lower = 1;
+  if (smallk_ok(g, false) && !nd4_gemm_force_tiled()) return launch_smallk<true>(h, g, batch);
   g.tiles_m = (int)((N + BM - 1) / BM); g.tiles_n = g.tiles_m;
   auto ok = [](const double* p, int64_t ld, int64_t st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0 && (st & 1) == 0; };
   const bool vec = ok(A, lda, sA) && ok(B, ldb, sB) && (K & 1) == 0;
