@@ -127,6 +127,13 @@ int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64
 int nd4hip_dldltrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
                                const double* Y, int64_t strideY, double* X);
 
+/* ---- hessenberg_decomp: replaces src/la/hessenberg.js:89-115 (kernel :27-86) -------------------------------
+ * A [batch,N,N] -> U, H [batch,N,N] with A = U H U^T, U orthogonal (last row and column = unit vector), H upper
+ * Hessenberg with exact zeros below the sub-diagonal. Same reflectors as the reference (rows finished from the bottom
+ * up, sign chosen against cancellation), so U and H agree with it to rounding. H may alias A in the _dev form. */
+int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H);
+int nd4hip_dgehrd_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H);
+
 /* ---- qr_lstsq: replaces src/la/qr.js:186-273 -------------------------------------
  * X [batch,I,J] = R[0:L,0:L]^-1 (Q^T Y)[0:L,:], L = min(M,I), rows L..I-1 zero; Q [batch,N,M], R [batch,M,I]
  * (as returned by dgeqrf_q for an N x I system: M = min(N,I)), Y [batch,N,J]. I > N is refused like qr.js:209.

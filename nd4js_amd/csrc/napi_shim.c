@@ -45,6 +45,7 @@ static gemm_fn p_dgemm[2];
 static getrf_fn p_dgetrf[2];
 static geqrf_fn p_dgeqrf[2];
 static geqrf_fn p_dgeqrf_full[2];
+static int (*p_dgehrd[2])(nd4hip_handle*, int64_t, int64_t, const double*, double*, double*);
 static int (*p_dgeqrf_qty[2])(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, double*, double*);
 static gesvdj_fn p_dgesvdj[2];
 static qrls_fn p_dqrls[2];
@@ -95,6 +96,7 @@ static int load_library(void) {
   SYM2(p_dgeqrf, "nd4hip_dgeqrf_q_batched");
   SYM2(p_dgeqrf_full, "nd4hip_dgeqrf_full_batched");
   SYM2(p_dgeqrf_qty, "nd4hip_dgeqrf_qty_batched");
+  SYM2(p_dgehrd, "nd4hip_dgehrd_batched");
   SYM2(p_dgesvdj, "nd4hip_dgesvdj_batched");
   SYM2(p_dgetrs, "nd4hip_dgetrs_batched");
   SYM2(p_dpotrf, "nd4hip_dpotrf_batched");
@@ -283,6 +285,18 @@ static napi_value js_dgeqrf_qty(napi_env env, napi_callback_info info) {
   SAME_SIDE(A.dev == Y.dev, "dgeqrf_qty_batched");
   if (ensure_handle(env)) return NULL;
   FAIL_IF(p_dgeqrf_qty[A.dev](g_handle, batch, M, N, L, (double*)A.p, (double*)Y.p));
+  return NULL;
+}
+/* dgehrd_batched(batch, N, A, U, H)   (hessenberg_decomp, hessenberg.js:89-115) */
+static napi_value js_dgehrd(napi_env env, napi_callback_info info) {
+  ARGS(5, "dgehrd_batched");
+  int64_t batch, N; opnd A, U, H;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &N) || F64(2, A) || F64(3, U) || F64(4, H)) return NULL;
+  NEED(batch >= 0 && N >= 0 && (size_t)(batch * N * N) <= A.len && (size_t)(batch * N * N) <= U.len && (size_t)(batch * N * N) <= H.len,
+       "dgehrd_batched: buffer too small");
+  SAME_SIDE(A.dev == U.dev && U.dev == H.dev, "dgehrd_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dgehrd[A.dev](g_handle, batch, N, (const double*)A.p, (double*)U.p, (double*)H.p));
   return NULL;
 }
 /* dgesvdj_batched(batch, M, N, A, U, sv, V) -> {sweeps, offnorm} */
@@ -496,6 +510,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_full_batched", NULL, js_dgeqrf_full, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_qty_batched", NULL, js_dgeqrf_qty, NULL, NULL, NULL, napi_default, NULL},
+    {"dgehrd_batched", NULL, js_dgehrd, NULL, NULL, NULL, napi_default, NULL},
     {"dgesvdj_batched", NULL, js_dgesvdj, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrs_batched", NULL, js_dgetrs, NULL, NULL, NULL, napi_default, NULL},
     {"dqrls_batched", NULL, js_dqrls, NULL, NULL, NULL, napi_default, NULL},

@@ -356,6 +356,29 @@ extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N
   return 0;
 }
 
+// ---- hessenberg_decomp (hessenberg.js:89-115)   
+extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && U && H, "nd4hip_dgehrd_batched: NULL pointer");
+  return nd4_gehrd(h, batch, N, A, U, H);
+}
+extern "C" int nd4hip_dgehrd_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
+  if (batch == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)(batch * N * N);
+  DevBuf dU, dH;
+  ND4_TRY(dU.alloc(n * D)); ND4_TRY(dH.alloc(n * D));
+  ND4_TRY(h2d(h, dH.p, A, n * D));
+  ND4_TRY(nd4hip_dgehrd_batched_dev(h, batch, N, (const double*)dH.p, (double*)dU.p, (double*)dH.p));      // in place on the copy
+  ND4_TRY(d2h(h, U, dU.p, n * D)); ND4_TRY(d2h(h, H, dH.p, n * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ QR
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");

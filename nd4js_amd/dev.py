@@ -273,3 +273,14 @@ def ldl_solve(LD, Y):
     b = _batch(lead)
     _lib.check(h.lib.nd4hip_dldltrs_batched_dev(h.ptr, b, N, J, _p(LD), N * N if b > 1 else 0, _p(Y), N * J if b > 1 else 0, _p(X)))
     return X
+
+
+def hessenberg_decomp(A):
+    _chk(A, "A")
+    N = A.shape[-1]
+    if A.dim() < 2 or A.shape[-2] != N:
+        raise ValueError("hessenberg_decomp(A): A must be square.")
+    U, H = torch.empty_like(A), torch.empty_like(A)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgehrd_batched_dev(h.ptr, _batch(A.shape[:-2]), N, _p(A), _p(U), _p(H)))
+    return U, H

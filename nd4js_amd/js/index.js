@@ -445,6 +445,19 @@ function makeLa(NDA, fallback) {
     return wrap(dev, [...lead, N, J], X);
   };
 
+  la.hessenberg_decomp = function hessenberg_decomp(A) {   // hessenberg.js:89-115
+    A = asarray(A);
+    if (A.ndim < 2) throw new Error('hessenberg_decomp(A): A must at least be 2D.');
+    const nd_ = A.ndim, N = A.shape[nd_ - 1];
+    if (N != A.shape[nd_ - 2]) throw new Error('hessenberg_decomp(A): A must be square.');
+    if (!gpuOk(A)) { if (fallback && fallback.hessenberg_decomp) return fallback.hessenberg_decomp(A); throw new Error('nd4hip.hessenberg_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const batch = prod(A.shape, 0, nd_ - 2), dev = isDev(A), temps = [];
+    const U = alloc(dev, batch * N * N), H = alloc(dev, batch * N * N);
+    native().dgehrd_batched(batch, N, view(opF64(A, dev, temps), 0), view(U, 0), view(H, 0));
+    release(temps);
+    return [wrap(dev, A.shape, U), wrap(dev, A.shape, H)];
+  };
+
   /* ---- least squares from a factorisation: qr_lstsq (qr.js:186-273), svd_lstsq / svd_solve (svd.js:66-228) ---- */
   la.qr_lstsq = function qr_lstsq(Q, R, y) {
     if (undefined == y) { y = R; [Q, R] = Q; }
@@ -523,7 +536,7 @@ function install(nd) {
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
                     qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve,
                     cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve,
-                    ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve};
+                    ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve, hessenberg_decomp: nd.la.hessenberg_decomp};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

@@ -485,3 +485,18 @@ def ldl_solve(LD, y, device=None):
     for cnt, (oL, oY), (sL, sY), b0 in _bcast_groups_n(tuple(lead), [LD.shape[:-2], y.shape[:-2]], [N * N, N * J]):
         _lib.check(h.lib.nd4hip_dldltrs_batched(h.ptr, cnt, N, J, _off(LD, oL), sL, _off(y, oY), sY, _off(X, b0 * N * J)))
     return X
+
+
+def hessenberg_decomp(A, device=None):
+    """hessenberg.js:89-115: (U, H) with A = U H U^T, H upper Hessenberg."""
+    A = np.asarray(A)
+    if A.ndim < 2:
+        raise ValueError("hessenberg_decomp(A): A must at least be 2D.")
+    A = _asarray(A, "hessenberg_decomp(A)")
+    N = A.shape[-1]
+    if A.shape[-2] != N:
+        raise ValueError("hessenberg_decomp(A): A must be square.")
+    U, H = np.empty_like(A), np.empty_like(A)
+    h = _lib.handle(device)
+    _lib.check(h.lib.nd4hip_dgehrd_batched(h.ptr, int(np.prod(A.shape[:-2], dtype=np.int64)), N, _ptr(A), _ptr(U), _ptr(H)))
+    return U, H

@@ -48,6 +48,7 @@ def lib():
         L.nd4o_cholesky_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_ldl_decomp.argtypes = [_i64, _i64, _dp, _dp]
         L.nd4o_ldl_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
+        L.nd4o_hessenberg_decomp.argtypes = [_i64, _dp, _dp]
         L.nd4o_qr_decomp_inplace.argtypes = [_i64, _i64, _i64, _dp, _dp]
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
@@ -303,3 +304,19 @@ def ldl_solve(LD, Y):
     X = np.empty(lead + (N, J))
     lib().nd4o_ldl_solve(int(np.prod(lead, dtype=np.int64)), N, J, _d(Lb), N * N, _d(Yb), N * J, _d(X))
     return X
+
+
+def hessenberg_decomp(A):
+    """hessenberg.js:89-115: returns (U, H) with A = U H U^T"""
+    A = _f64(A)
+    if A.ndim < 2:
+        raise ValueError("hessenberg_decomp(A): A must at least be 2D.")
+    N = A.shape[-1]
+    if A.shape[-2] != N:
+        raise ValueError("hessenberg_decomp(A): A must be square.")
+    H = A.copy()
+    U = np.zeros_like(H)
+    h2, u2 = H.reshape(-1, N, N), U.reshape(-1, N, N)
+    for b in range(h2.shape[0] - 1, -1, -1):
+        lib().nd4o_hessenberg_decomp(N, _d(u2[b]), _d(h2[b]))
+    return U, H

@@ -316,6 +316,27 @@ if (what === 'ldl') {
   caseLdl('ldl_200', 173, [200, 200]);
 }
 
+if (what === 'hess') {
+  /* SURVEY §8f N4: hessenberg_decomp (hessenberg.js:27-115) */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const caseHess = (name, seed, shape, family) => {
+    const a = fill(seed, numel(shape)), N = shape[shape.length - 1];
+    if (family === 'sparse') { const m = fill(seed + 1000, a.length); for (let i = 0; i < a.length; i++) if (m[i] > 0.6) a[i] = 0; }
+    if (family === 'hess') for (let o = 0; o < a.length; o += N * N) for (let i = 0; i < N; i++) for (let j = 0; j + 1 < i; j++) a[o + i * N + j] = 0;   // already Hessenberg: every step is skipped
+    const [U, H] = nd.la.hessenberg_decomp(NDA(shape, a));
+    record(name, {op: 'hessenberg_decomp', seed, shape, family: family || 'dense'}, {U: [U.data, Array.from(U.shape)], H: [H.data, Array.from(H.shape)]});
+  };
+  caseHess('hess_1x1', 181, [1, 1]);
+  caseHess('hess_2x2', 182, [2, 2]);
+  caseHess('hess_3x3', 183, [3, 3]);
+  caseHess('hess_17', 184, [17, 17]);
+  caseHess('hess_batch', 185, [2, 3, 12, 12]);
+  caseHess('hess_sparse_40', 186, [40, 40], 'sparse');
+  caseHess('hess_already_20', 187, [20, 20], 'hess');
+  caseHess('hess_100', 188, [100, 100]);
+  caseHess('hess_257', 189, [257, 257]);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

@@ -310,6 +310,64 @@ void nd4o_ldl_solve(int64_t batch, int64_t N, int64_t J, const double* LD, int64
   }
 }
 
+/* ------------------------------------------------------------------ Hessenberg (hessenberg.js) */
+/* src/la/norm.js:22-67 FrobeniusNorm: scaled sum of squares (include / resultIncl) */
+typedef struct { double sum, max; } fro_t;
+static void fro_include(fro_t* f, double x) {
+  x = fabs(x);
+  if (x != 0) {
+    if (f->max < x) { const double s = f->max / x; f->sum *= s * s; f->max = x; }
+    x /= f->max;
+    f->sum += x * x;
+  }
+}
+static double fro_result_incl(const fro_t* f, double x) {
+  x = fabs(x);
+  double sum = f->sum, max = f->max;
+  if (x != 0) {
+    if (max < x) { const double s = max / x; sum *= s * s; max = x; }
+    x /= max;
+    sum += x * x;
+  }
+  return isfinite(max) ? sqrt(sum) * max : max;
+}
+/* src/la/hessenberg.js:27-86 _hessenberg_decomp on one matrix: A = U H U^T, H upper Hessenberg; rows are finished from
+ * the bottom up with Householder reflectors acting on the leading columns; U (zero on entry) uses its last row as scratch. */
+void nd4o_hessenberg_decomp(int64_t N, double* U, double* H) {
+  for (int64_t i = N - 1; i-- > 0;) U[N * i + i] = 1.0;
+  const int64_t lastRow = N * (N - 1);
+  for (int64_t i = N; --i > 1;) {
+    const int64_t rowI = N * i, ii = rowI + (i - 1);
+    fro_t nrm = {0.0, 0.0};
+    for (int64_t j = i - 1; j-- > 0;) fro_include(&nrm, H[rowI + j]);
+    if (nrm.max == 0) continue;
+    const double norm = fro_result_incl(&nrm, H[ii]) * (H[ii] > 0 ? -1 : +1);
+    H[ii] -= norm;
+    fro_include(&nrm, H[ii]);
+    const double max = nrm.max, div = sqrt(nrm.sum);
+    for (int64_t j = i; j-- > 0;) H[rowI + j] = H[rowI + j] / max * 1.4142135623730951 / div;     /* Math.SQRT2 */
+    for (int64_t j = i; j-- > 0;) {                                   /* right of H */
+      double sum = 0;
+      for (int64_t k = i; k-- > 0;) sum += H[N * j + k] * H[rowI + k];
+      for (int64_t k = i; k-- > 0;) H[N * j + k] -= H[rowI + k] * sum;
+    }
+    for (int64_t k = 0; k < N; k++) U[lastRow + k] = 0.0;              /* left of H */
+    for (int64_t j = i; j-- > 0;)
+      for (int64_t k = N; k-- > 0;) U[lastRow + k] += H[N * j + k] * H[rowI + j];
+    for (int64_t j = i; j-- > 0;)
+      for (int64_t k = N; k-- > 0;) H[N * j + k] -= H[rowI + j] * U[lastRow + k];
+    for (int64_t j = N - 1; j-- > 0;) {                               /* right of U */
+      double sum = 0;
+      for (int64_t k = i; k-- > 0;) sum += U[N * j + k] * H[rowI + k];
+      for (int64_t k = i; k-- > 0;) U[N * j + k] -= H[rowI + k] * sum;
+    }
+    for (int64_t k = rowI; k < ii; k++) H[k] = 0.0;
+    H[ii] = norm;
+  }
+  for (int64_t k = lastRow; k < N * N - 1; k++) U[k] = 0.0;
+  U[N * N - 1] = 1;
+}
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace: Givens elimination of A (M x N) in place, the same rotations applied to the
  * rows of Y (M x L). The bundle /root/reference/dist/nd.js does not export this function, so it is pinned through the
  * reference's own test oracle (qr_test.js:213-225): A == R and Y == Q^T Y of qr_decomp_full. */

@@ -63,6 +63,9 @@ void nd4o_ldl_decomp(int64_t batch, int64_t N, const double* S, double* LD);
 /* src/la/ldl.js:133-201 ldl_solve core (:93-130): X = L^-T D^-1 L^-1 Y (strides in doubles, 0 = broadcast) */
 void nd4o_ldl_solve(int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD, const double* Y, int64_t strideY, double* X);
 
+/* src/la/hessenberg.js:27-86 on one matrix: U [N,N] zero on entry, H [N,N] = A on entry; A = U H U^T on exit */
+void nd4o_hessenberg_decomp(int64_t N, double* U, double* H);
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace on one matrix: A [M,N] <- R, Y [M,L] <- Q^T Y */
 void nd4o_qr_decomp_inplace(int64_t M, int64_t N, int64_t L, double* A, double* Y);
 

@@ -78,3 +78,15 @@ def sym_indefinite(seed, shape):
     d = r[..., idx, idx]
     D[..., idx, idx] = np.where(d >= 0, 1 + d, -1 + d)
     return oracle.matmul2(oracle.matmul2(L, D), np.swapaxes(L, -1, -2).copy())
+
+
+def hess_input(seed, shape, family):
+    """inputs of oracle/gen_golden.js `hess`"""
+    from nd4js_amd import rng
+    a = rng.matrix(seed, *shape)
+    N = shape[-1]
+    if family == "sparse":
+        a[rng.matrix(seed + 1000, *shape) > 0.6] = 0.0
+    if family == "hess":
+        a = a * (np.arange(N)[None, :] + 1 >= np.arange(N)[:, None])       # zero below the sub-diagonal
+    return a

@@ -43,6 +43,7 @@ if (mode === 'cpu') {
   assert.throws(() => la.svd_lstsq(fill(1, [2, 2]), new la.NDArray(Int32Array.of(2), Float64Array.of(1, NaN)), fill(3, [2, 2]), fill(4, [2, 1])), /NaN or Infinity/);
   assert.throws(() => la.svd_solve(fill(1, [4, 3]), fill(2, [3]), fill(3, [3, 3]), fill(4, [4, 1])), /System not square/);
   assert.throws(() => la.cholesky_decomp(fill(1, [2, 3])), /must be quadratic/);
+  assert.throws(() => la.hessenberg_decomp(fill(1, [2, 3])), /A must be square/);
   assert.throws(() => la.ldl_solve(fill(1, [3, 3]), fill(2, [4, 1])), /ldl_solve\(LD,y\): LD and y don't match/);
   assert.throws(() => la.cholesky_solve(fill(1, [3, 3]), fill(2, [4, 1])), /L and y don't match/);
   const g = la.bcastGroups([3, 4], [3, 1], [4], 35, 42);
@@ -144,6 +145,8 @@ if (mode === 'gpu') {
     assert.ok(relerr(LD.data, refLD.data) <= 1e-12);
     const X = la.ldl_solve(new la.NDArray(Int32Array.of(N, N), refLD.data), fill(m.seedY, m.shapeY));
     assert.deepStrictEqual(Array.from(X.shape), refX.shape); assert.ok(relerr(X.data, refX.data) <= 1e-12); }
+  { const m = man.hess_17, [U, H] = la.hessenberg_decomp(fill(m.seed, m.shape));
+    assert.ok(relerr(U.data, npy('hess_17', 'U').data) <= 1e-12 && relerr(H.data, npy('hess_17', 'H').data) <= 1e-12); }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }

@@ -1,0 +1,70 @@
+"""GPU parity of hessenberg_decomp (hessenberg.js:27-115) through the C ABI, against reference-generated
+goldens and the oracle; properties as in hessenberg_test.js (A = U H U^T, U orthogonal, H upper Hessenberg)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_cases
+from families import hess_input
+from nd4js_amd import rng
+
+pytestmark = pytest.mark.gpu
+EPS = 2.0 ** -52
+
+
+@pytest.fixture(scope="module")
+def la():
+    from nd4js_amd import la as _la
+    return _la
+
+
+def check_props(a, u, h):
+    N = a.shape[-1]
+    assert np.array_equal(np.tril(h, -2), np.zeros_like(h))                             # exact zeros below the sub-diagonal
+    assert np.abs(u @ np.swapaxes(u, -1, -2) - np.eye(N)).max() <= 8 * EPS * max(N, 4)
+    scale = max(np.linalg.norm(a), 1e-300)
+    assert np.linalg.norm(u @ h @ np.swapaxes(u, -1, -2) - a) <= 32 * EPS * max(N, 4) * scale
+    if N > 1:                                                                            # hessenberg.js:88-89
+        assert np.all(u[..., -1, :-1] == 0) and np.all(u[..., :-1, -1] == 0) and np.all(u[..., -1, -1] == 1)
+
+
+@pytest.mark.parametrize("name", golden_cases(op="hessenberg_decomp"))
+def test_hessenberg_golden(la, golden, name):
+    g = golden(name)
+    a = hess_input(g.seed, tuple(g.shape), g.family)
+    u, h = la.hessenberg_decomp(a)
+    assert u.shape == g["U"].shape and h.shape == g["H"].shape
+    check_props(a, u, h)
+    N = a.shape[-1]
+    tol = 64 * EPS * max(N, 4)
+    assert np.abs(h - g["H"]).max() <= tol * max(np.abs(a).max(), 1e-300) * max(N, 4) ** 0.5
+    assert np.abs(u - g["U"]).max() <= tol * 4
+    if g.family == "hess":                                                               # every step skipped: nothing changes
+        assert np.array_equal(h, a) and np.array_equal(u, np.eye(N))
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 31, 32, 33, 64, 200, 257, 512, 1024])
+def test_hessenberg_sizes(la, N):
+    a = rng.matrix(6200 + N, N, N)
+    u, h = la.hessenberg_decomp(a)
+    check_props(a, u, h)
+    if N <= 257:
+        uo, ho = oracle.hessenberg_decomp(a)
+        assert np.abs(h - ho).max() <= 1e-11 and np.abs(u - uo).max() <= 1e-11
+    ev, evr = np.sort_complex(np.linalg.eigvals(h)), np.sort_complex(np.linalg.eigvals(a))   # similarity keeps the spectrum
+    if N <= 257:
+        assert np.abs(ev - evr).max() <= 1e-8 * max(np.abs(evr).max(), 1)
+
+
+def test_hessenberg_batch_and_device(la):
+    import torch
+    from nd4js_amd import dev
+    a = rng.matrix(6300, 2, 3, 48, 48)
+    u, h = la.hessenberg_decomp(a)
+    check_props(a, u, h)
+    ud, hd = dev.hessenberg_decomp(torch.from_numpy(a).cuda())
+    assert np.array_equal(ud.cpu().numpy(), u) and np.array_equal(hd.cpu().numpy(), h)
+    with pytest.raises(ValueError, match="must be square"):
+        la.hessenberg_decomp(np.ones((2, 3)))
+    with pytest.raises(ValueError, match="at least be 2D"):
+        la.hessenberg_decomp(np.ones(3))

@@ -213,3 +213,14 @@ def test_ldl_bit_exact(golden, name):
     if "X" in g.files:
         x = oracle.ldl_solve(LD, rng.matrix(g.seedY, *g.shapeY))
         assert x.shape == g["X"].shape and np.array_equal(x, g["X"])
+
+
+# ---- hessenberg_decomp (hessenberg.js:27-115) ----
+from families import hess_input  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_cases(op="hessenberg_decomp"))
+def test_hessenberg_bit_exact(golden, name):
+    g = golden(name)
+    u, h = oracle.hessenberg_decomp(hess_input(g.seed, tuple(g.shape), g.family))
+    assert np.array_equal(u, g["U"]) and np.array_equal(h, g["H"])
