@@ -127,6 +127,13 @@ int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64
 int nd4hip_dldltrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
                                const double* Y, int64_t strideY, double* X);
 
+/* ---- bidiag_decomp: replaces src/la/bidiag.js:245-319 (kernels :32-242) -----------------------------------
+ * A [batch,M,N] -> U [batch,M,K], B [batch,K,J] upper bidiagonal (exact zeros elsewhere), V [batch,J,N] with A = U B V,
+ * K = min(M,N), J = K for M >= N and K+1 for M < N; U has orthonormal columns, V orthonormal rows. The signs follow
+ * the reference's three branches (see csrc/bidiag.hip), so U, B, V agree with it to rounding. */
+int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V);
+int nd4hip_dgebrd_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V);
+
 /* ---- hessenberg_decomp: replaces src/la/hessenberg.js:89-115 (kernel :27-86) -------------------------------
  * A [batch,N,N] -> U, H [batch,N,N] with A = U H U^T, U orthogonal (last row and column = unit vector), H upper
  * Hessenberg with exact zeros below the sub-diagonal. Same reflectors as the reference (rows finished from the bottom

@@ -50,6 +50,8 @@ SIGNATURES = {
     "nd4hip_dldltrf_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp]),
     "nd4hip_dldltrs_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
     "nd4hip_dldltrs_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),
+    "nd4hip_dgebrd_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp]),
+    "nd4hip_dgebrd_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp]),
     "nd4hip_dgehrd_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, c_dp]),
     "nd4hip_dgehrd_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_dp, c_dp, c_dp]),
     "nd4hip_dqrls_batched_dev": (c_int, [ctypes.c_void_p] + [c_i64] * 5 + [c_dp, c_i64, c_dp, c_i64, c_dp, c_i64, c_dp]),

@@ -1,0 +1,300 @@
+// Batched bidiagonalisation on the device.
+//
+// Replaces src/la/bidiag.js:245-319 (bidiag_decomp; kernels _bidiag_decomp_vert :32-110, _square :113-161, _horiz
+// :164-242): A [M,N] = U B V with B [I,J] upper bidiagonal, U [M,I] with orthonormal columns, V [J,N] with orthonormal
+// rows, I = min(M,N), J = I for M >= N and I+1 for M < N.
+//
+// The reference eliminates column i with plane rotations and the tail of row i with one Householder reflector. The
+// factorisation is unique up to the signs of the columns of U / rows of V, and those signs are pinned as follows:
+//   * right side: the very same reflector convention as the reference (FrobeniusNorm scaling, B[i,i+1] = -sign(x) |x..|,
+//     bidiag.js:66-76): the reflector does not depend on the sign of the row it is built from, so V agrees whatever the
+//     left side did;
+//   * left side: Householder reflectors (LAPACK-style), then the reference's Givens sign convention is imposed on
+//     (U, rows of B) afterwards by nd4_givens_signs: B[i,i] >= 0 and det U = +1 for M <= N (rotations without
+//     normalisation, bidiag.js:123-136 / :183-195), positive leading minors of U's top block for M > N (the c >= 0
+//     normalisation of bidiag.js:49-61 preserves the sign of the pivot, exactly like qr.js:111-115).
+// Unblocked (BLAS-2): every step is two matrix-vector products and two rank-1 updates on the trailing block, bound by HBM;
+// U and V are accumulated afterwards by applying the stored reflectors backwards to the identity.
+#include "nd4hip_internal.h"
+
+namespace {
+
+constexpr int GR = 8;             // rows per workgroup of the weighted column sum (2 per wave): many small workgroups
+
+__device__ __forceinline__ double blk_max(double v, double* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  return v;
+}
+__device__ __forceinline__ double blk_sum(double v, double* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  __syncthreads();
+  return v;
+}
+
+// ---- reflector generation ----
+// left: column i of W, rows i..M-1 -> u (u_i = 1) into column i of UL (ld K), tau, W[i,i] = beta, zeros below.
+// LAPACK dlarfg with a max-scaled norm: H = I - tau u u^T maps the column to beta e_1.
+__global__ __launch_bounds__(256) void bd_vec_col(double* __restrict__ Wm, int M, int N, int i, double* __restrict__ ULm, int K,
+                                                   double* __restrict__ tauLm) {
+  __shared__ double s_red[4];
+  double* W = Wm + (long)blockIdx.x * M * N;
+  double* UL = ULm + (long)blockIdx.x * M * K;
+  const int t = threadIdx.x;
+  double mx = 0.0;
+  for (int r = i + 1 + t; r < M; r += 256) mx = fmax(mx, fabs(W[(long)r * N + i]));
+  mx = blk_max(mx, s_red);
+  for (int r = t; r < i; r += 256) UL[(long)r * K + i] = 0.0;
+  if (mx == 0.0) {                                                  // nothing below the diagonal: H = I
+    for (int r = i + 1 + t; r < M; r += 256) UL[(long)r * K + i] = 0.0;
+    if (t == 0) { UL[(long)i * K + i] = 1.0; tauLm[(long)blockIdx.x * K + i] = 0.0; }
+    return;
+  }
+  const double alpha = W[(long)i * N + i];
+  const double sc = fmax(mx, fabs(alpha));
+  double ss = 0.0;
+  for (int r = i + 1 + t; r < M; r += 256) { const double x = W[(long)r * N + i] / sc; ss += x * x; }
+  ss = blk_sum(ss, s_red);
+  const double a1 = alpha / sc;
+  const double nrm = sqrt(ss + a1 * a1) * sc;
+  const double beta = alpha > 0 ? -nrm : nrm;
+  const double tau = (beta - alpha) / beta;
+  const double inv = 1.0 / (alpha - beta);
+  for (int r = i + 1 + t; r < M; r += 256) { UL[(long)r * K + i] = W[(long)r * N + i] * inv; W[(long)r * N + i] = 0.0; }
+  if (t == 0) { UL[(long)i * K + i] = 1.0; W[(long)i * N + i] = beta; tauLm[(long)blockIdx.x * K + i] = tau; }
+}
+
+// right: row i of W, columns first = i+1 .. N-1 -> unit vector v into row i of VR (zeros elsewhere), flag, finished row.
+// The reference's convention (bidiag.js:66-76): norm = -sign(x_first) |x|, v = (x - norm e) / max / sqrt(sum), H = I - 2 v v^T.
+__global__ __launch_bounds__(256) void bd_vec_row(double* __restrict__ Wm, int M, int N, int i, double* __restrict__ VRm, int K,
+                                                   int* __restrict__ flagRm) {
+  __shared__ double s_red[4];
+  double* row = Wm + (long)blockIdx.x * M * N + (long)i * N;
+  double* v = VRm + (long)blockIdx.x * K * N + (long)i * N;
+  const int t = threadIdx.x, first = i + 1;
+  double m1 = 0.0;
+  for (int j = first + 1 + t; j < N; j += 256) m1 = fmax(m1, fabs(row[j]));
+  m1 = blk_max(m1, s_red);
+  if (m1 == 0.0) {                                                  // NORM.max === 0 -> continue
+    for (int j = t; j < N; j += 256) v[j] = 0.0;
+    if (t == 0) flagRm[(long)blockIdx.x * K + i] = 0;
+    return;
+  }
+  const double x0 = row[first];
+  const double mx = fmax(m1, fabs(x0));
+  double ss = 0.0;
+  for (int j = first + t; j < N; j += 256) { const double x = row[j] / mx; ss += x * x; }
+  ss = blk_sum(ss, s_red);
+  const double nrm = (isfinite(mx) ? sqrt(ss) * mx : mx) * (x0 > 0 ? -1.0 : 1.0);
+  const double head = x0 - nrm;
+  const double mx2 = fmax(m1, fabs(head));
+  double s2 = 0.0;
+  for (int j = first + 1 + t; j < N; j += 256) { const double x = row[j] / mx2; s2 += x * x; }
+  s2 = blk_sum(s2, s_red);
+  { const double x = head / mx2; s2 += x * x; }
+  const double div = sqrt(s2);
+  for (int j = t; j < N; j += 256) {
+    double vj = 0.0;
+    if (j >= first) vj = (j == first ? head : row[j]) / mx2 / div;
+    v[j] = vj;
+  }
+  __syncthreads();
+  for (int j = first + 1 + t; j < N; j += 256) row[j] = 0.0;
+  if (t == 0) { row[first] = nrm; flagRm[(long)blockIdx.x * K + i] = 1; }
+}
+
+// ---- the three BLAS-2 building blocks on a sub-block X[r0:r1, c0:c1] (row-major, ld) ----
+struct Blk { double* X; long ld, sX; int r0, r1, c0, c1; };
+
+// zpart[p][c] = sum over the GR rows of group p of a[r] * X[r,c]      (a = column `acol` of A2, ld lda)
+__global__ __launch_bounds__(256) void bd_colsum(Blk b, const double* __restrict__ Am, long lda, long sA, int acol,
+                                                  const double* __restrict__ gate, long sGate, int gidx, double* __restrict__ zpart, long sZ, int ncols_total) {
+  const long m = blockIdx.z;
+  if (gate && gate[m * sGate + gidx] == 0.0) return;
+  const double* X = b.X + m * b.sX;
+  const double* a = Am + m * sA + acol;
+  const int rg = b.r0 + blockIdx.y * GR;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ double s_x[4][64];
+  const int c = b.c0 + blockIdx.x * 64 + lane;
+  double acc = 0.0;
+  if (c < b.c1) {
+#pragma unroll
+    for (int q = 0; q < GR / 4; q++) {
+      const int r = rg + wave * (GR / 4) + q;
+      if (r < b.r1) acc += a[(long)r * lda] * X[(long)r * b.ld + c];
+    }
+  }
+  s_x[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < b.c1) zpart[m * sZ + (long)blockIdx.y * ncols_total + c] = (s_x[0][lane] + s_x[1][lane]) + (s_x[2][lane] + s_x[3][lane]);
+}
+// z[c] = scale * sum_p zpart[p][c], scale = tau[gidx] (or 1); 32 columns per workgroup, 8 thread groups per column
+__global__ __launch_bounds__(256) void bd_colsum_reduce(int c0, int c1, int P, const double* __restrict__ zpart, long sZ, int ncols_total,
+                                                         const double* __restrict__ gate, long sGate, int gidx, double* __restrict__ z, long sz) {
+  const long m = blockIdx.y;
+  double scale = 1.0;
+  if (gate) { scale = gate[m * sGate + gidx]; if (scale == 0.0) return; }
+  __shared__ double s_part[8][32];
+  const int cc = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = c0 + blockIdx.x * 32 + cc;
+  double x = 0.0;
+  if (c < c1)
+    for (int p = g; p < P; p += 8) x += zpart[m * sZ + (long)p * ncols_total + c];
+  s_part[g][cc] = x;
+  __syncthreads();
+  if (g == 0 && c < c1) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += s_part[q][cc];
+    z[m * sz + c] = scale * s;
+  }
+}
+// y[r] = scale * sum_c X[r,c] * bvec[c]; one wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void bd_rowdot(Blk b, const double* __restrict__ bm, long sB, double scale, const int* __restrict__ flag, long sF, int fidx,
+                                                  double* __restrict__ y, long sy) {
+  const long m = blockIdx.y;
+  if (flag && !flag[m * sF + fidx]) return;
+  const double* X = b.X + m * b.sX;
+  const double* bv = bm + m * sB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = b.r0 + blockIdx.x * 4 + wave;
+  if (r >= b.r1) return;
+  double acc = 0.0;
+  for (int c = b.c0 + lane; c < b.c1; c += 64) acc += X[(long)r * b.ld + c] * bv[c];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) y[m * sy + r] = scale * acc;
+}
+// X[r,c] -= p[r] * q[c]   (p: stride ldp, e.g. a column of UL; q contiguous)
+__global__ __launch_bounds__(256) void bd_rank1(Blk b, const double* __restrict__ pm, long ldp, long sP, const double* __restrict__ qm, long sQ,
+                                                 const double* __restrict__ gate, long sGate, const int* __restrict__ flag, long sF, int gidx) {
+  const long m = blockIdx.z;
+  if (gate && gate[m * sGate + gidx] == 0.0) return;
+  if (flag && !flag[m * sF + gidx]) return;
+  double* X = b.X + m * b.sX;
+  const double* p = pm + m * sP;
+  const double* q = qm + m * sQ;
+  const int c = b.c0 + blockIdx.x * 256 + threadIdx.x;
+  if (c >= b.c1) return;
+  const double qc = q[c];
+  const int rg = b.r0 + blockIdx.y * 16;
+#pragma unroll 4
+  for (int r = rg; r < rg + 16 && r < b.r1; r++) X[(long)r * b.ld + c] -= p[(long)r * ldp] * qc;
+}
+
+__global__ void bd_set_identity(double* __restrict__ Xm, int rows, int cols) {
+  const long base = (long)blockIdx.z * rows * cols;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) Xm[base + (long)r * cols + j] = (r == j) ? 1.0 : 0.0;
+}
+// B [K, J] <- diagonal and super-diagonal of W [M, N], zeros elsewhere
+__global__ void bd_extract(const double* __restrict__ Wm, int M, int N, double* __restrict__ Bm, int K, int J) {
+  const double* W = Wm + (long)blockIdx.z * M * N;
+  double* B = Bm + (long)blockIdx.z * K * J;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= J) return;
+  for (int i = blockIdx.y; i < K; i += gridDim.y) B[(long)i * J + j] = (j == i || j == i + 1) ? W[(long)i * N + j] : 0.0;
+}
+
+struct BdWs { double* z; double* y; double* zpart; long sV, sZ; int ncols_total; };
+
+// X[r0:r1, c0:c1] -= a * (scale * a^T X): a = column acol of A2 (ld lda); gate = tau array (scale and on/off switch)
+int reflect_left(nd4hip_handle* h, int batch, const Blk& b, const double* A2, long lda, long sA, int acol, const double* tau, long sTau, int tidx, const BdWs& ws) {
+  const int nr = b.r1 - b.r0, nc = b.c1 - b.c0;
+  if (nr <= 0 || nc <= 0) return 0;
+  const int P = (nr + GR - 1) / GR;
+  hipLaunchKernelGGL(bd_colsum, dim3((unsigned)((nc + 63) / 64), (unsigned)P, (unsigned)batch), dim3(256), 0, h->stream,
+                     b, A2, lda, sA, acol, tau, sTau, tidx, ws.zpart, ws.sZ, ws.ncols_total);
+  hipLaunchKernelGGL(bd_colsum_reduce, dim3((unsigned)((nc + 31) / 32), (unsigned)batch), dim3(256), 0, h->stream,
+                     b.c0, b.c1, P, ws.zpart, ws.sZ, ws.ncols_total, tau, sTau, tidx, ws.z, ws.sV);
+  hipLaunchKernelGGL(bd_rank1, dim3((unsigned)((nc + 255) / 256), (unsigned)((nr + 15) / 16), (unsigned)batch), dim3(256), 0, h->stream,
+                     b, A2 + acol, lda, sA, ws.z, ws.sV, tau, sTau, (const int*)nullptr, 0l, tidx);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+// X[r0:r1, c0:c1] -= (2 X v) v^T with the unit vector v (row vidx of VR); flag switches the step off
+int reflect_right(nd4hip_handle* h, int batch, const Blk& b, const double* v, long sVR, const int* flag, long sF, int fidx, const BdWs& ws) {
+  const int nr = b.r1 - b.r0, nc = b.c1 - b.c0;
+  if (nr <= 0 || nc <= 0) return 0;
+  hipLaunchKernelGGL(bd_rowdot, dim3((unsigned)((nr + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, b, v, sVR, 2.0, flag, sF, fidx, ws.y, ws.sV);
+  hipLaunchKernelGGL(bd_rank1, dim3((unsigned)((nc + 255) / 256), (unsigned)((nr + 15) / 16), (unsigned)batch), dim3(256), 0, h->stream,
+                     b, ws.y, 1l, ws.sV, v, sVR, (const double*)nullptr, 0l, flag, sF, fidx);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// A [batch, M, N] -> U [batch, M, K], B [batch, K, J], V [batch, J, N]; K = min(M, N), J = K (M >= N) or K + 1
+int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A, double* U, double* B, double* V) {
+  ND4_CHECK_ARG(M64 < 32768 && N64 < 32768 && batch64 < 65536, "nd4_gebrd: extent out of range");
+  const int M = (int)M64, N = (int)N64, batch = (int)batch64;
+  if (M == 0 || N == 0 || batch == 0) return 0;
+  const int K = M < N ? M : N, J = M >= N ? K : K + 1;
+  const int mx = M > N ? M : N;
+  const int Pmax = (M + GR - 1) / GR;
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  const size_t nd = (size_t)batch * ((size_t)M * N + (size_t)M * K + (size_t)K * N + (size_t)K + 2 * (size_t)mx + (size_t)Pmax * mx);
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * nd + sizeof(int) * (size_t)batch * (2 * (size_t)K + 2) + 256, &p));
+  double* W = static_cast<double*>(p);
+  double* UL = W + (size_t)batch * M * N;
+  double* VR = UL + (size_t)batch * M * K;
+  double* tauL = VR + (size_t)batch * K * N;
+  BdWs ws;
+  ws.z = tauL + (size_t)batch * K; ws.y = ws.z + (size_t)batch * mx; ws.zpart = ws.y + (size_t)batch * mx;
+  ws.sV = mx; ws.sZ = (long)Pmax * mx; ws.ncols_total = mx;
+  int* flagR = reinterpret_cast<int*>(ws.zpart + (size_t)batch * Pmax * mx);
+  int* flips = flagR + (size_t)batch * K + 1;
+  const long sW = (long)M * N, sUL = (long)M * K, sVRm = (long)K * N;
+  ND4_HIP(hipMemcpyAsync(W, A, sizeof(double) * (size_t)batch * sW, hipMemcpyDeviceToDevice, h->stream));
+  ND4_HIP(hipMemsetAsync(VR, 0, sizeof(double) * (size_t)batch * sVRm, h->stream));
+  ND4_HIP(hipMemsetAsync(flagR, 0, sizeof(int) * (size_t)batch * K, h->stream));
+
+  // ---- factorisation ----
+  for (int i = 0; i < K; i++) {
+    hipLaunchKernelGGL(bd_vec_col, dim3((unsigned)batch), dim3(256), 0, h->stream, W, M, N, i, UL, K, tauL);
+    {
+      Blk b{W, N, sW, i, M, i + 1, N};                       // (I - tau u u^T) on the columns to the right
+      ND4_TRY(reflect_left(h, batch, b, UL, K, sUL, i, tauL, K, i, ws));
+    }
+    if (i + 1 < N - 1) {                                     // something to the right of the super-diagonal
+      hipLaunchKernelGGL(bd_vec_row, dim3((unsigned)batch), dim3(256), 0, h->stream, W, M, N, i, VR, K, flagR);
+      Blk b{W, N, sW, i + 1, M, i + 1, N};                   // rows below, same reflector from the right
+      ND4_TRY(reflect_right(h, batch, b, VR + (long)i * N, sVRm, flagR, K, i, ws));
+    }
+  }
+  {
+    const unsigned gy = (unsigned)(K < 512 ? K : 512);
+    hipLaunchKernelGGL(bd_extract, dim3((unsigned)((J + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, W, M, N, B, K, J);
+  }
+  // ---- U = H_0 ... H_{K-1} [I; 0]: reflectors applied backwards ----
+  {
+    const unsigned gy = (unsigned)(M < 512 ? M : 512);
+    hipLaunchKernelGGL(bd_set_identity, dim3((unsigned)((K + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, U, M, K);
+  }
+  for (int i = K - 1; i >= 0; i--) {
+    Blk b{U, K, (long)M * K, i, M, i, K};
+    ND4_TRY(reflect_left(h, batch, b, UL, K, sUL, i, tauL, K, i, ws));
+  }
+  // ---- V = first J rows of H^R_{r-1} ... H^R_0 ----
+  {
+    const unsigned gy = (unsigned)(J < 512 ? J : 512);
+    hipLaunchKernelGGL(bd_set_identity, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, V, J, N);
+  }
+  for (int k = K - 1; k >= 0; k--) {
+    if (!(k + 1 < N - 1)) continue;
+    Blk b{V, N, (long)J * N, k + 1, J, k + 1, N};
+    ND4_TRY(reflect_right(h, batch, b, VR + (long)k * N, sVRm, flagR, K, k, ws));
+  }
+  ND4_HIP(hipGetLastError());
+  // ---- the reference's sign convention on (columns of U, rows of B) ----
+  return nd4_givens_signs(h, batch, M, K, J, M > N, U, K, (long)M * K, B, J, (long)K * J, tauL, K, flips);
+}

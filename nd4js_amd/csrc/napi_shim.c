@@ -45,6 +45,7 @@ static gemm_fn p_dgemm[2];
 static getrf_fn p_dgetrf[2];
 static geqrf_fn p_dgeqrf[2];
 static geqrf_fn p_dgeqrf_full[2];
+static int (*p_dgebrd[2])(nd4hip_handle*, int64_t, int64_t, int64_t, const double*, double*, double*, double*);
 static int (*p_dgehrd[2])(nd4hip_handle*, int64_t, int64_t, const double*, double*, double*);
 static int (*p_dgeqrf_qty[2])(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, double*, double*);
 static gesvdj_fn p_dgesvdj[2];
@@ -97,6 +98,7 @@ static int load_library(void) {
   SYM2(p_dgeqrf_full, "nd4hip_dgeqrf_full_batched");
   SYM2(p_dgeqrf_qty, "nd4hip_dgeqrf_qty_batched");
   SYM2(p_dgehrd, "nd4hip_dgehrd_batched");
+  SYM2(p_dgebrd, "nd4hip_dgebrd_batched");
   SYM2(p_dgesvdj, "nd4hip_dgesvdj_batched");
   SYM2(p_dgetrs, "nd4hip_dgetrs_batched");
   SYM2(p_dpotrf, "nd4hip_dpotrf_batched");
@@ -285,6 +287,20 @@ static napi_value js_dgeqrf_qty(napi_env env, napi_callback_info info) {
   SAME_SIDE(A.dev == Y.dev, "dgeqrf_qty_batched");
   if (ensure_handle(env)) return NULL;
   FAIL_IF(p_dgeqrf_qty[A.dev](g_handle, batch, M, N, L, (double*)A.p, (double*)Y.p));
+  return NULL;
+}
+/* dgebrd_batched(batch, M, N, A, U, B, V)   (bidiag_decomp, bidiag.js:245-319) */
+static napi_value js_dgebrd(napi_env env, napi_callback_info info) {
+  ARGS(7, "dgebrd_batched");
+  int64_t batch, M, N; opnd A, U, B, V;
+  if (get_i64(env, a[0], &batch) || get_i64(env, a[1], &M) || get_i64(env, a[2], &N) || F64(3, A) || F64(4, U) || F64(5, B) || F64(6, V)) return NULL;
+  NEED(batch >= 0 && M >= 0 && N >= 0, "dgebrd_batched: negative extent");
+  const int64_t K = M < N ? M : N, J = M >= N ? K : K + 1;
+  NEED((size_t)(batch * M * N) <= A.len && (size_t)(batch * M * K) <= U.len && (size_t)(batch * K * J) <= B.len && (size_t)(batch * J * N) <= V.len,
+       "dgebrd_batched: buffer too small");
+  SAME_SIDE(A.dev == U.dev && U.dev == B.dev && B.dev == V.dev, "dgebrd_batched");
+  if (ensure_handle(env)) return NULL;
+  FAIL_IF(p_dgebrd[A.dev](g_handle, batch, M, N, (const double*)A.p, (double*)U.p, (double*)B.p, (double*)V.p));
   return NULL;
 }
 /* dgehrd_batched(batch, N, A, U, H)   (hessenberg_decomp, hessenberg.js:89-115) */
@@ -510,6 +526,7 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_full_batched", NULL, js_dgeqrf_full, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_qty_batched", NULL, js_dgeqrf_qty, NULL, NULL, NULL, napi_default, NULL},
+    {"dgebrd_batched", NULL, js_dgebrd, NULL, NULL, NULL, napi_default, NULL},
     {"dgehrd_batched", NULL, js_dgehrd, NULL, NULL, NULL, napi_default, NULL},
     {"dgesvdj_batched", NULL, js_dgesvdj, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrs_batched", NULL, js_dgetrs, NULL, NULL, NULL, napi_default, NULL},

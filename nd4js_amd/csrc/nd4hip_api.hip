@@ -356,6 +356,30 @@ extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N
   return 0;
 }
 
+// ---- bidiag_decomp (bidiag.js:245-319)   
+extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_CHECK_ARG(A && U && B && V, "nd4hip_dgebrd_batched: NULL pointer");
+  return nd4_gebrd(h, batch, M, N, A, U, B, V);
+}
+extern "C" int nd4hip_dgebrd_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
+  ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  ND4_HIP(hipSetDevice(h->device));
+  const int64_t K = M < N ? M : N, J = M >= N ? K : K + 1;
+  const size_t nA = (size_t)(batch * M * N), nU = (size_t)(batch * M * K), nB = (size_t)(batch * K * J), nV = (size_t)(batch * J * N);
+  DevBuf dA, dU, dB, dV;
+  ND4_TRY(dA.alloc(nA * D)); ND4_TRY(dU.alloc(nU * D)); ND4_TRY(dB.alloc(nB * D)); ND4_TRY(dV.alloc(nV * D));
+  ND4_TRY(h2d(h, dA.p, A, nA * D));
+  ND4_TRY(nd4hip_dgebrd_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dU.p, (double*)dB.p, (double*)dV.p));
+  ND4_TRY(d2h(h, U, dU.p, nU * D)); ND4_TRY(d2h(h, B, dB.p, nB * D)); ND4_TRY(d2h(h, V, dV.p, nV * D));
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // ---- hessenberg_decomp (hessenberg.js:89-115)   
 extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");

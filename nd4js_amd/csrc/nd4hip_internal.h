@@ -61,6 +61,7 @@ int nd4_trsm_t(nd4hip_handle* h, int64_t batch, int64_t M, int64_t J, const doub
 int nd4_trsm_t_ex(nd4hip_handle* h, bool unit, int64_t batch, int64_t M, int64_t J, const double* T, int64_t ldT, int64_t sT, double* X, int64_t sX);
 int nd4_ldltrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD);
 int nd4_ldltrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t sLD, const double* Y, int64_t sY, double* X);
+int nd4_gebrd(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V);
 int nd4_gehrd(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H);
 int nd4_potrf(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L, int* flags);
 int nd4_potrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t sL, const double* Y, int64_t sY, double* X);
@@ -71,6 +72,8 @@ int nd4_svdls(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, 
 int nd4_getrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t sLU, const int32_t* P, int64_t sP,
               const double* Y, int64_t sY, double* X);
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
+                     double* R, long ldr, long sR, const double* taus, long sTau, int* flips);
 int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R, bool full);
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);

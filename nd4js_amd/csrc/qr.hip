@@ -643,25 +643,39 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   }
 
   // ---- reference sign convention ----
-  if (tall && !full) {
+  return nd4_givens_signs(h, batch, M, L, N, tall && !full, Q, Lq, sQ, R, N, (long)Lr * N, ws.taus, ws.sTau, ws.flips);
+}
+
+// Sign convention of the reference's Givens-built factors, applied to a Householder-built pair (Q [M, >= L] with leading
+// dimension ldq, R [L, ncols] with leading dimension ldr; column j of Q and row j of R are flipped together):
+//   lu_rule = false (qr_decomp_full, the square / wide branches): R_jj >= 0 wherever a reflector was needed (tau_j != 0),
+//             and det Q = +1 (plane rotations) decides the last one when Q is square (M == L);
+//   lu_rule = true  (the c >= 0 branches for tall input, qr.js:97-139 / bidiag.js:49-61): every leading principal minor of
+//             Q's top L x L block is positive = positive pivots in its LU factorisation WITHOUT pivoting.
+// flips: L ints per matrix of scratch.
+int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
+                     double* R, long ldr, long sR, const double* taus, long sTau, int* flips) {
+  if (lu_rule) {
     Nd4WsScope scope2(h);
     void* q = nullptr;
-    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * N * N + sizeof(int32_t) * (size_t)batch * N, &q));
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * L * L + sizeof(int32_t) * (size_t)batch * L, &q));
     double* LUq = static_cast<double*>(q);
-    int32_t* Pq = reinterpret_cast<int32_t*>(LUq + (size_t)batch * N * N);
-    ND4_TRY(nd4_copy_matrix(h, N, N, Q, Lq, LUq, N, batch, sQ, (long)N * N));
-    ND4_TRY(nd4_getrf_nopivot(h, batch, N, LUq, LUq, Pq));
-    hipLaunchKernelGGL(qr_flips_tall, dim3((unsigned)(((long)batch * N + 255) / 256)), dim3(256), 0, h->stream, LUq, N, ws.flips, batch);
-  } else
-  hipLaunchKernelGGL(qr_flips, dim3((unsigned)batch), dim3(256), 0, h->stream,
-                     R, (long)N, (long)Lr * N, ws.taus, ws.sTau, M, N, L, ws.flips, batch);
+    int32_t* Pq = reinterpret_cast<int32_t*>(LUq + (size_t)batch * L * L);
+    ND4_TRY(nd4_copy_matrix(h, L, L, Q, ldq, LUq, L, batch, sQ, (long)L * L));
+    ND4_TRY(nd4_getrf_nopivot(h, batch, L, LUq, LUq, Pq));
+    hipLaunchKernelGGL(qr_flips_tall, dim3((unsigned)(((long)batch * L + 255) / 256)), dim3(256), 0, h->stream, LUq, L, flips, batch);
+  } else {
+    // qr_flips decides the parity flip by "M <= N": pass N = M when Q is square, N = M - 1 otherwise
+    hipLaunchKernelGGL(qr_flips, dim3((unsigned)batch), dim3(256), 0, h->stream,
+                       R, ldr, sR, taus, sTau, M, (M == L ? M : M - 1), L, flips, batch);
+  }
   {
     const unsigned gy = (unsigned)(L < 512 ? L : 512);
-    hipLaunchKernelGGL(qr_flip_rows, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream,
-                       R, (long)N, (long)Lr * N, L, N, ws.flips, L);
+    hipLaunchKernelGGL(qr_flip_rows, dim3((unsigned)((ncols + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream,
+                       R, ldr, sR, L, ncols, flips, L);
     const unsigned gq = (unsigned)(M < 512 ? M : 512);
     hipLaunchKernelGGL(qr_flip_cols, dim3((unsigned)((L + 255) / 256), gq, (unsigned)batch), dim3(256), 0, h->stream,
-                       Q, (long)Lq, sQ, M, L, ws.flips, L);
+                       Q, ldq, sQ, M, L, flips, L);
   }
   ND4_HIP(hipGetLastError());
   return 0;

@@ -284,3 +284,19 @@ def hessenberg_decomp(A):
     h = _h(A)
     _lib.check(h.lib.nd4hip_dgehrd_batched_dev(h.ptr, _batch(A.shape[:-2]), N, _p(A), _p(U), _p(H)))
     return U, H
+
+
+def bidiag_decomp(A):
+    _chk(A, "A")
+    if A.dim() < 2:
+        raise ValueError("bidiag_decomp(A): A must be at least 2D.")
+    M, N = A.shape[-2:]
+    I = min(M, N)
+    J = I if M >= N else I + 1
+    lead = tuple(A.shape[:-2])
+    U = torch.empty(lead + (M, I), dtype=torch.float64, device=A.device)
+    B = torch.empty(lead + (I, J), dtype=torch.float64, device=A.device)
+    V = torch.empty(lead + (J, N), dtype=torch.float64, device=A.device)
+    h = _h(A)
+    _lib.check(h.lib.nd4hip_dgebrd_batched_dev(h.ptr, _batch(lead), M, N, _p(A), _p(U), _p(B), _p(V)))
+    return U, B, V

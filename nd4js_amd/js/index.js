@@ -445,6 +445,21 @@ function makeLa(NDA, fallback) {
     return wrap(dev, [...lead, N, J], X);
   };
 
+  la.bidiag_decomp = function bidiag_decomp(A) {           // bidiag.js:245-319
+    A = asarray(A);
+    if (A.ndim < 2) throw new Error('bidiag_decomp(A): A must be at least 2D.');
+    if (String(dtypeOf(A)).startsWith('complex')) throw new Error('bidiag_decomp(A): complex A not yet supported.');
+    if (!gpuOk(A)) { if (fallback && fallback.bidiag_decomp) return fallback.bidiag_decomp(A); throw new Error('nd4hip.bidiag_decomp: dtype ' + dtypeOf(A) + ' is not accelerated.'); }
+    const nd_ = A.ndim, M = A.shape[nd_ - 2], N = A.shape[nd_ - 1], I = Math.min(M, N), J = M >= N ? I : I + 1, batch = prod(A.shape, 0, nd_ - 2);
+    const Us = Int32Array.from(A.shape), Bs = Int32Array.from(A.shape), Vs = Int32Array.from(A.shape);
+    Us[nd_ - 1] = I; Bs[nd_ - 2] = I; Bs[nd_ - 1] = J; Vs[nd_ - 2] = J;
+    const dev = isDev(A), temps = [];
+    const U = alloc(dev, batch * M * I), B = alloc(dev, batch * I * J), V = alloc(dev, batch * J * N);
+    native().dgebrd_batched(batch, M, N, view(opF64(A, dev, temps), 0), view(U, 0), view(B, 0), view(V, 0));
+    release(temps);
+    return [wrap(dev, Us, U), wrap(dev, Bs, B), wrap(dev, Vs, V)];
+  };
+
   la.hessenberg_decomp = function hessenberg_decomp(A) {   // hessenberg.js:89-115
     A = asarray(A);
     if (A.ndim < 2) throw new Error('hessenberg_decomp(A): A must at least be 2D.');
@@ -536,7 +551,7 @@ function install(nd) {
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
                     qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve,
                     cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve,
-                    ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve, hessenberg_decomp: nd.la.hessenberg_decomp};
+                    ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve, hessenberg_decomp: nd.la.hessenberg_decomp, bidiag_decomp: nd.la.bidiag_decomp};
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);

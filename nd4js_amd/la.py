@@ -500,3 +500,21 @@ def hessenberg_decomp(A, device=None):
     h = _lib.handle(device)
     _lib.check(h.lib.nd4hip_dgehrd_batched(h.ptr, int(np.prod(A.shape[:-2], dtype=np.int64)), N, _ptr(A), _ptr(U), _ptr(H)))
     return U, H
+
+
+def bidiag_decomp(A, device=None):
+    """bidiag.js:245-319: (U [..., M, I], B [..., I, J], V [..., J, N]) with A = U B V, B upper bidiagonal."""
+    A = np.asarray(A)
+    if A.ndim < 2:
+        raise ValueError("bidiag_decomp(A): A must be at least 2D.")
+    if np.iscomplexobj(A):
+        raise ValueError("bidiag_decomp(A): complex A not yet supported.")
+    A = _asarray(A, "bidiag_decomp(A)")
+    M, N = A.shape[-2:]
+    I = min(M, N)
+    J = I if M >= N else I + 1
+    lead = A.shape[:-2]
+    U, B, V = np.empty(lead + (M, I)), np.empty(lead + (I, J)), np.empty(lead + (J, N))
+    h = _lib.handle(device)
+    _lib.check(h.lib.nd4hip_dgebrd_batched(h.ptr, int(np.prod(lead, dtype=np.int64)), M, N, _ptr(A), _ptr(U), _ptr(B), _ptr(V)))
+    return U, B, V

@@ -49,6 +49,7 @@ def lib():
         L.nd4o_ldl_decomp.argtypes = [_i64, _i64, _dp, _dp]
         L.nd4o_ldl_solve.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_hessenberg_decomp.argtypes = [_i64, _dp, _dp]
+        L.nd4o_bidiag_decomp.argtypes = [_i64, _i64, _dp, _dp, _dp, _dp, _dp]
         L.nd4o_qr_decomp_inplace.argtypes = [_i64, _i64, _i64, _dp, _dp]
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
@@ -320,3 +321,20 @@ def hessenberg_decomp(A):
     for b in range(h2.shape[0] - 1, -1, -1):
         lib().nd4o_hessenberg_decomp(N, _d(u2[b]), _d(h2[b]))
     return U, H
+
+
+def bidiag_decomp(A):
+    """bidiag.js:245-319: (U [..., M, I], B [..., I, J], V [..., J, N]) with A = U B V"""
+    A = _f64(A)
+    if A.ndim < 2:
+        raise ValueError("bidiag_decomp(A): A must be at least 2D.")
+    M, N = A.shape[-2:]
+    I = min(M, N)
+    J = I if M >= N else I + 1
+    lead = A.shape[:-2]
+    U, B, V = np.empty(lead + (M, I)), np.empty(lead + (I, J)), np.empty(lead + (J, N))
+    a2, u2, b2, v2 = A.reshape(-1, M, N), U.reshape(-1, M, I), B.reshape(-1, I, J), V.reshape(-1, J, N)
+    tmp = np.empty(N)
+    for k in range(a2.shape[0]):
+        lib().nd4o_bidiag_decomp(M, N, _d(a2[k]), _d(u2[k]), _d(b2[k]), _d(v2[k]), _d(tmp))
+    return U, B, V

@@ -337,6 +337,32 @@ if (what === 'hess') {
   caseHess('hess_257', 189, [257, 257]);
 }
 
+if (what === 'bidiag') {
+  /* SURVEY §8f N4: bidiag_decomp (bidiag.js:32-319), all three shape branches */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const caseBd = (name, seed, shape, sparse) => {
+    const a = fill(seed, numel(shape));
+    if (sparse) { const m = fill(seed + 1000, a.length); for (let i = 0; i < a.length; i++) if (m[i] > 0.6) a[i] = 0; }
+    const [U, B, V] = nd.la.bidiag_decomp(NDA(shape, a));
+    record(name, {op: 'bidiag_decomp', seed, shape, sparse: !!sparse},
+           {U: [U.data, Array.from(U.shape)], B: [B.data, Array.from(B.shape)], V: [V.data, Array.from(V.shape)]});
+  };
+  caseBd('bidiag_1x1', 191, [1, 1]);
+  caseBd('bidiag_2x2', 192, [2, 2]);
+  caseBd('bidiag_sq_17', 193, [17, 17]);
+  caseBd('bidiag_sq_64', 194, [64, 64]);
+  caseBd('bidiag_vert_20x7', 195, [20, 7]);
+  caseBd('bidiag_vert_65x64', 196, [65, 64]);
+  caseBd('bidiag_vert_5x1', 197, [5, 1]);
+  caseBd('bidiag_horiz_7x20', 198, [7, 20]);
+  caseBd('bidiag_horiz_1x5', 199, [1, 5]);
+  caseBd('bidiag_horiz_40x41', 200, [40, 41]);
+  caseBd('bidiag_batch', 201, [2, 3, 9, 12]);
+  caseBd('bidiag_sparse_sq_30', 202, [30, 30], true);
+  caseBd('bidiag_sparse_vert', 203, [33, 12], true);
+  caseBd('bidiag_sq_130', 204, [130, 130]);
+}
+
 if (what === 'c2') {
   const N = 4096, A = fill(5, N * N), B = fill(6, N * N);
   const t = Date.now();

@@ -368,6 +368,162 @@ void nd4o_hessenberg_decomp(int64_t N, double* U, double* H) {
   U[N * N - 1] = 1;
 }
 
+/* ------------------------------------------------------------------ bidiagonalisation (bidiag.js) */
+static void transpose_inplace_sq(int64_t N, double* A) {                 /* transpose_inplace.js:21-30 */
+  for (int64_t i = 0; i < N; i++)
+    for (int64_t j = i + 1; j < N; j++) { const double t = A[N * i + j]; A[N * i + j] = A[N * j + i]; A[N * j + i] = t; }
+}
+/* Householder that leaves only entry `first` of row[first .. first+len-1] (bidiag.js:66-76 / :125-135 / :182-195): the
+ * normalised vector (|v| = 1) overwrites v[first..]; returns 0 if there was nothing to eliminate (NORM.max === 0). */
+static int bidiag_row_householder(const double* row, double* v, int64_t first, int64_t end, double* norm_out) {
+  fro_t nrm = {0.0, 0.0};
+  for (int64_t j = end; --j > first;) fro_include(&nrm, row[j]);
+  if (nrm.max == 0) return 0;
+  const double norm = fro_result_incl(&nrm, row[first]) * (row[first] > 0 ? -1 : +1);
+  double head = row[first] - norm;
+  fro_include(&nrm, head);
+  const double max = nrm.max, div = sqrt(nrm.sum);
+  for (int64_t j = first; j < end; j++) v[j] = (j == first ? head : row[j]) / max / div;
+  *norm_out = norm;
+  return 1;
+}
+/* X[j, first..end) -= 2 (X[j,:] . v) v for rows j in [j0, j1): "apply householder to right of ..." */
+static void bidiag_apply_right(double* X, int64_t ld, int64_t j0, int64_t j1, const double* v, int64_t first, int64_t end) {
+  for (int64_t j = j0; j < j1; j++) {
+    double sum = 0;
+    for (int64_t k = first; k < end; k++) sum += X[ld * j + k] * v[k];
+    sum *= 2;
+    for (int64_t k = first; k < end; k++) X[ld * j + k] -= v[k] * sum;
+  }
+}
+/* src/la/bidiag.js:113-161 _bidiag_decomp_square: U, V zero on entry, B = A on entry */
+static void bidiag_square1(int64_t N, double* U, double* B, double* V, double* tmp) {
+  for (int64_t i = N; i-- > 0;) { U[N * i + i] = 1; V[N * i + i] = 1; }
+  for (int64_t i = 0; i < N - 1; i++) {
+    const int64_t ii = N * i + i;
+    for (int64_t j = i; ++j < N;) {
+      const int64_t ji = N * j + i;
+      const double B_ji = B[ji]; if (B_ji == 0) continue;
+      double c, s, norm; nd4o_giv_rot_qr(B[ii], B_ji, &c, &s, &norm);
+      B[ji] = 0; if (s == 0) continue;
+      B[ii] = norm;
+      giv_rot_rows(B, N - 1 - i, ii + 1, ji + 1, c, s);
+      giv_rot_rows(U, 1 + j, N * i, N * j, c, s);
+    }
+    double norm;
+    if (!bidiag_row_householder(B + N * i, tmp, i + 1, N, &norm)) continue;
+    for (int64_t j = i + 1; j < N; j++) B[N * i + j] = tmp[j];
+    bidiag_apply_right(V, N, 0, N, B + N * i, i + 1, N);
+    bidiag_apply_right(B, N, i + 1, N, B + N * i, i + 1, N);
+    B[ii + 1] = norm;
+    for (int64_t k = ii + 2; k < N * (i + 1); k++) B[k] = 0.0;
+  }
+  transpose_inplace_sq(N, V);
+  transpose_inplace_sq(N, U);
+}
+/* src/la/bidiag.js:32-110 _bidiag_decomp_vert (M >= N): U [M,N] = A on entry, B, V [N,N] zero on entry */
+static void bidiag_vert1(int64_t M, int64_t N, double* U, double* B, double* V, double* tmp) {
+  for (int64_t i = N; i-- > 0;) V[N * i + i] = 1;
+  for (int64_t i = 0; i < N; i++) {
+    const int64_t ii = N * i + i;
+    for (int64_t j = i; ++j < M;) {
+      const int64_t ji = N * j + i;
+      const double B_ji = U[ji]; if (B_ji == 0) continue;
+      double c, s, norm; nd4o_giv_rot_qr(U[ii], B_ji, &c, &s, &norm);
+      if (s != 0) {
+        if (c < 0) { c *= -1; s *= -1; norm *= -1; }
+        giv_rot_rows(U, N - 1 - i, ii + 1, ji + 1, c, s);
+        U[ii] = norm;
+      }
+      U[ji] = s;
+    }
+    if (i < N - 2) {
+      double norm;
+      if (!bidiag_row_householder(U + N * i, tmp, i + 1, N, &norm)) continue;
+      for (int64_t j = i + 1; j < N; j++) U[N * i + j] = tmp[j];
+      bidiag_apply_right(V, N, 0, N, U + N * i, i + 1, N);
+      bidiag_apply_right(U, N, i + 1, M, U + N * i, i + 1, N);
+      U[ii + 1] = norm;
+      for (int64_t k = ii + 2; k < N * (i + 1); k++) U[k] = 0.0;
+    }
+  }
+  transpose_inplace_sq(N, V);
+  for (int64_t i = N; --i > 0;) { B[N * i + i] = U[N * i + i]; B[N * (i - 1) + i] = U[N * (i - 1) + i]; }
+  B[0] = U[0];
+  for (int64_t i = 0; i < N; i++)
+    for (int64_t j = i; j < N; j++) U[N * i + j] = (i == j) ? 1.0 : 0.0;
+  for (int64_t i = N; i-- > 0;)
+    for (int64_t j = M; --j > i;) {
+      const double s = U[N * j + i]; if (s == 0) continue;
+      U[N * j + i] = 0;
+      const double c = sqrt((1 + s) * (1 - s));
+      giv_rot_rows(U, N - i, N * j + i, N * i + i, c, s);
+    }
+}
+/* src/la/bidiag.js:164-242 _bidiag_decomp_horiz (M < N): U [M,M], B [M,M+1] zero on entry; V [(M+1),N] holds A in its
+ * rows 1..M on entry (bidiag.js:288-291) */
+static void bidiag_horiz1(int64_t M, int64_t N, double* U, double* B, double* Vbuf) {
+  double* V = Vbuf + N;                                              /* V_off + N */
+  for (int64_t i = M; i-- > 0;) U[M * i + i] = 1;
+  for (int64_t i = 0; i < M && i < N - 1; i++) {
+    const int64_t ii = N * i + i;
+    for (int64_t j = i; ++j < M;) {
+      const int64_t ji = N * j + i;
+      const double B_ji = V[ji]; if (B_ji == 0) continue;
+      double c, s, norm; nd4o_giv_rot_qr(V[ii], B_ji, &c, &s, &norm);
+      V[ji] = 0; if (s == 0) continue;
+      V[ii] = norm;
+      giv_rot_rows(V, N - 1 - i, ii + 1, ji + 1, c, s);
+      giv_rot_rows(U, 1 + j, M * i, M * j, c, s);
+    }
+    double* above = V + N * (i - 1);                                 /* householder goes to row (i-1) of the shifted buffer */
+    fro_t nrm = {0.0, 0.0};
+    for (int64_t j = N - 1;;) {
+      const double V_j = above[j] = V[N * i + j]; if (--j <= i) break;
+      fro_include(&nrm, V_j);
+    }
+    if (nrm.max == 0) { above[i + 1] = 0; continue; }
+    const double norm = fro_result_incl(&nrm, above[i + 1]) * (above[i + 1] > 0 ? -1 : +1);
+    above[i + 1] -= norm;
+    fro_include(&nrm, above[i + 1]);
+    const double max = nrm.max, div = sqrt(nrm.sum);
+    for (int64_t j = i; ++j < N;) above[j] = above[j] / max / div;
+    bidiag_apply_right(V, N, i + 1, M, above, i + 1, N);
+    V[ii + 1] = norm;
+  }
+  transpose_inplace_sq(M, U);
+  for (int64_t i = M; i-- > 0;) {
+    B[(M + 1) * i + (i + 1)] = i < N - 1 ? V[N * i + (i + 1)] : 0;
+    B[(M + 1) * i + i] = V[N * i + i];
+  }
+  for (int64_t i = (M < N - 1 ? M : N - 1);;) {
+    --i;
+    for (int64_t k = 0; k < N; k++) V[N * i + k] = 0.0;
+    V[N * i + (i + 1)] = 1;
+    if (i < 0) break;
+    const double* above = V + N * (i - 1);
+    bidiag_apply_right(V, N, i, M, above, i + 1, N);
+  }
+}
+/* src/la/bidiag.js:245-319 bidiag_decomp on one matrix: A [M,N] -> U [M,I], B [I,J], V [J,N], I = min(M,N), J = I (M >= N)
+ * or I+1 (M < N). tmp: N doubles. */
+void nd4o_bidiag_decomp(int64_t M, int64_t N, const double* A, double* U, double* B, double* V, double* tmp) {
+  if (M == N) {
+    for (int64_t e = 0; e < N * N; e++) { B[e] = A[e]; U[e] = 0.0; V[e] = 0.0; }
+    bidiag_square1(N, U, B, V, tmp);
+  } else if (M > N) {
+    for (int64_t e = 0; e < M * N; e++) U[e] = A[e];
+    for (int64_t e = 0; e < N * N; e++) { B[e] = 0.0; V[e] = 0.0; }
+    bidiag_vert1(M, N, U, B, V, tmp);
+  } else {
+    for (int64_t e = 0; e < N; e++) V[e] = 0.0;
+    for (int64_t e = 0; e < M * N; e++) V[N + e] = A[e];
+    for (int64_t e = 0; e < M * M; e++) U[e] = 0.0;
+    for (int64_t e = 0; e < M * (M + 1); e++) B[e] = 0.0;
+    bidiag_horiz1(M, N, U, B, V);
+  }
+}
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace: Givens elimination of A (M x N) in place, the same rotations applied to the
  * rows of Y (M x L). The bundle /root/reference/dist/nd.js does not export this function, so it is pinned through the
  * reference's own test oracle (qr_test.js:213-225): A == R and Y == Q^T Y of qr_decomp_full. */

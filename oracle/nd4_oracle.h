@@ -66,6 +66,10 @@ void nd4o_ldl_solve(int64_t batch, int64_t N, int64_t J, const double* LD, int64
 /* src/la/hessenberg.js:27-86 on one matrix: U [N,N] zero on entry, H [N,N] = A on entry; A = U H U^T on exit */
 void nd4o_hessenberg_decomp(int64_t N, double* U, double* H);
 
+/* src/la/bidiag.js:245-319 bidiag_decomp (kernels :32-242) on one matrix: A [M,N] -> U [M,I], B [I,J] upper bidiagonal,
+ * V [J,N] with A = U B V; I = min(M,N), J = I (M >= N) or I+1 (M < N). tmp: N doubles. */
+void nd4o_bidiag_decomp(int64_t M, int64_t N, const double* A, double* U, double* B, double* V, double* tmp);
+
 /* src/la/qr.js:146-183 _qr_decomp_inplace on one matrix: A [M,N] <- R, Y [M,L] <- Q^T Y */
 void nd4o_qr_decomp_inplace(int64_t M, int64_t N, int64_t L, double* A, double* Y);
 

@@ -147,6 +147,8 @@ if (mode === 'gpu') {
     assert.deepStrictEqual(Array.from(X.shape), refX.shape); assert.ok(relerr(X.data, refX.data) <= 1e-12); }
   { const m = man.hess_17, [U, H] = la.hessenberg_decomp(fill(m.seed, m.shape));
     assert.ok(relerr(U.data, npy('hess_17', 'U').data) <= 1e-12 && relerr(H.data, npy('hess_17', 'H').data) <= 1e-12); }
+  { for (const c of ['bidiag_sq_17', 'bidiag_vert_20x7', 'bidiag_horiz_7x20']) { const m = man[c], [U, B, V] = la.bidiag_decomp(fill(m.seed, m.shape));
+      for (const [x, k] of [[U, 'U'], [B, 'B'], [V, 'V']]) { const ref = npy(c, k); assert.deepStrictEqual(Array.from(x.shape), ref.shape); assert.ok(relerr(x.data, ref.data) <= 1e-11, c + ' ' + k); } } }
   { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
   console.log('node gpu checks ok');
 }

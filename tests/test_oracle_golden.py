@@ -224,3 +224,19 @@ def test_hessenberg_bit_exact(golden, name):
     g = golden(name)
     u, h = oracle.hessenberg_decomp(hess_input(g.seed, tuple(g.shape), g.family))
     assert np.array_equal(u, g["U"]) and np.array_equal(h, g["H"])
+
+
+# ---- bidiag_decomp (bidiag.js:32-319) ----
+def bidiag_input(g):
+    a = rng.matrix(g.seed, *g.shape)
+    if g.sparse:
+        a[rng.matrix(g.seed + 1000, *g.shape) > 0.6] = 0.0
+    return a
+
+
+@pytest.mark.parametrize("name", golden_cases(op="bidiag_decomp"))
+def test_bidiag_bit_exact(golden, name):
+    g = golden(name)
+    u, b, v = oracle.bidiag_decomp(bidiag_input(g))
+    assert u.shape == g["U"].shape and b.shape == g["B"].shape and v.shape == g["V"].shape
+    assert np.array_equal(b, g["B"]) and np.array_equal(u, g["U"]) and np.array_equal(v, g["V"])

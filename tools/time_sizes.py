@@ -17,9 +17,9 @@ for n in ns:
     S.diagonal().add_(float(n))
     for op in ops:
         fn = {"lu": lambda: dev.lu_decomp(A), "qr": lambda: dev.qr_decomp(A), "svd": lambda: dev.svd_decomp(A),
-              "chol": lambda: dev.cholesky_decomp(S), "hess": lambda: dev.hessenberg_decomp(A), "ldl": lambda: dev.ldl_decomp(S), "matmul": lambda: dev.matmul2(A, A)}[op]
+              "chol": lambda: dev.cholesky_decomp(S), "hess": lambda: dev.hessenberg_decomp(A), "bidiag": lambda: dev.bidiag_decomp(A), "ldl": lambda: dev.ldl_decomp(S), "matmul": lambda: dev.matmul2(A, A)}[op]
         fn(); torch.cuda.synchronize()
-        reps = 1 if op in ("svd", "hess") else 3
+        reps = 1 if op in ("svd", "hess", "bidiag") else 3
         t = time.perf_counter()
         for _ in range(reps):
             fn()
