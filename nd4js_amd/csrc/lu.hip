@@ -12,6 +12,8 @@
 //   lu_trsm    U12 = L11^-1 * A12 (unit lower 16x16 in LDS, one thread per column).
 //   nd4_gemm   A22 -= L21 * U12 on the fp64 MFMA GEMM (gemm.hip).
 #include "nd4hip_internal.h"
+#include "dpp.h"
+#include <type_traits>
 #include <cfloat>
 
 namespace {
@@ -60,7 +62,6 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
   __shared__ int s_piv;
   __shared__ double s_u[NB];
   double* A = LU + blockIdx.x * strideM;
-  int32_t* p = P + (long)blockIdx.x * N;
   int32_t* ip = ipiv + (long)blockIdx.x * N;
   const int t = threadIdx.x, T = blockDim.x;
   const int c = t & (NB - 1), g = t >> 4, G = T >> 4;
@@ -76,7 +77,6 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
     if (nopivot) piv = jc;
     if (t == 0) {
       ip[jc] = piv;
-      if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
     }
     if (piv != jc && t < nb) {
       double* a = A + (long)jc * N + j0 + t; double* b = A + (long)piv * N + j0 + t;
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
   __shared__ PivCand s_red[8];
   __shared__ double s_u[NB], s_j[NB];
   double* A = LU + blockIdx.x * strideM;
-  int32_t* p = P + (long)blockIdx.x * N;
   int32_t* ip = ipiv + (long)blockIdx.x * N;
   const int t = threadIdx.x, wave = t >> 6;
   double a[R][NB];
@@ -155,8 +154,7 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
       const int piv = nopivot ? jc : best.idx;
       if (t == 0) {
         ip[jc] = piv;
-        if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
-      }
+        }
       // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
       const int pt = (piv - j0) & 511, pi = (piv - j0) >> 9;
       if (t == pt) {
@@ -226,7 +224,6 @@ __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, in
   __shared__ int s_piv;
   __shared__ double s_u[NB], s_j[NB];
   double* A = LU + blockIdx.x * strideM;
-  int32_t* p = P + (long)blockIdx.x * N;
   int32_t* ip = ipiv + (long)blockIdx.x * N;
   const int t = threadIdx.x, T = 1024;
   const int c = t & (NB - 1), g = t >> 4;
@@ -260,7 +257,6 @@ __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, in
     if (nopivot) piv = jc;
     if (t == 0) {
       ip[jc] = piv;
-      if (piv != jc) { int32_t tmp = p[jc]; p[jc] = p[piv]; p[piv] = tmp; }
     }
     // publish the pivot row (its owner group) and, if it moves, the displaced row jc
     const int pg = (piv - j0) & 63, pi = (piv - j0) >> 6;     // owner group / slot of row piv
@@ -342,9 +338,34 @@ __global__ __launch_bounds__(256) void lu_trsm(double* __restrict__ LU, int N, l
     if (i < nb) A[(long)(j0 + i) * N + col] = x[i];
 }
 
-__global__ void iota_kernel(int32_t* __restrict__ P, int N, long total) {
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i < total) P[i] = (int32_t)(i % N);
+// P = the identity with the recorded row interchanges applied in order (lu.js:59-61 swaps P together with the rows).
+// The panel kernels only record ipiv: the dependent global load/store chain of the swap used to sit on the critical
+// path of every column (thread 0 arrived ~1000 cycles late at the barrier). One workgroup per matrix, P in LDS.
+__global__ __launch_bounds__(256) void lu_build_perm(int32_t* __restrict__ Pm, const int32_t* __restrict__ ipiv, int N, int nopivot) {
+  extern __shared__ int32_t s_p[];
+  int32_t* P = Pm + (long)blockIdx.x * N;
+  const int32_t* ip = ipiv + (long)blockIdx.x * N;
+  for (int i = threadIdx.x; i < N; i += 256) s_p[i] = i;
+  __syncthreads();
+  if (threadIdx.x == 0 && !nopivot)
+    for (int j = 0; j < N; j++) {
+      const int pv = ip[j];
+      if (pv != j) { const int32_t tmp = s_p[j]; s_p[j] = s_p[pv]; s_p[pv] = tmp; }
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 256) P[i] = s_p[i];
+}
+// the same for N beyond the LDS budget: straight in global memory
+__global__ void lu_build_perm_global(int32_t* __restrict__ Pm, const int32_t* __restrict__ ipiv, int N, int nopivot) {
+  int32_t* P = Pm + (long)blockIdx.x * N;
+  const int32_t* ip = ipiv + (long)blockIdx.x * N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) P[i] = i;
+  __syncthreads();
+  if (threadIdx.x == 0 && !nopivot)
+    for (int j = 0; j < N; j++) {
+      const int pv = ip[j];
+      if (pv != j) { const int32_t tmp = P[j]; P[j] = P[pv]; P[pv] = tmp; }
+    }
 }
 
 template <int R>
@@ -364,7 +385,6 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   const long strideM = (long)N * N;
   if (LU != A) ND4_HIP(hipMemcpyAsync(LU, A, sizeof(double) * batch * strideM, hipMemcpyDeviceToDevice, h->stream));
   const long total = (long)batch * N;
-  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, N, total);
   void* ws = nullptr;
   Nd4WsScope scope(h);
   ND4_TRY(nd4_ws_alloc(h, sizeof(int32_t) * total, &ws));
@@ -402,6 +422,10 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
                        1.0, base + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
     }
   }
+  if ((size_t)N * sizeof(int32_t) <= 60 * 1024)
+    hipLaunchKernelGGL(lu_build_perm, dim3((unsigned)batch), dim3(256), (size_t)N * sizeof(int32_t), h->stream, P, ipiv, N, nopivot);
+  else
+    hipLaunchKernelGGL(lu_build_perm_global, dim3((unsigned)batch), dim3(256), 0, h->stream, P, ipiv, N, nopivot);
   ND4_HIP(hipGetLastError());
   return 0;
 }
