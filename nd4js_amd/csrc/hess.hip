@@ -20,6 +20,7 @@ constexpr int HR = 4 * RW;        // rows per workgroup (and per partial of x)
 struct HessWs {
   double* v; double* y; double* yu; double* w; double* xpart; int* skip;   // per matrix: v, y, yu, w [N]; xpart [P][N]; skip
   long sV, sX;                                                      // strides per matrix
+  double* vstore; int nstore;                                       // all reflectors as columns (N x nstore per matrix), or null
 };
 
 __device__ __forceinline__ double block_max(double v, double* s_red) {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void hess_vec(double* __restrict__ Hm, int N, 
   double m1 = 0.0;
   for (int j = t; j < ii; j += 256) m1 = fmax(m1, fabs(row[j]));
   m1 = block_max(m1, s_red);
+  double* vcol = ws.vstore ? ws.vstore + (long)blockIdx.x * N * ws.nstore + (N - 1 - i) : nullptr;   // column N-1-i (processing order)
   if (m1 == 0.0) {                                                  // NORM.max === 0 -> continue (:46)
     for (int j = t; j < N; j += 256) v[j] = 0.0;
     if (t == 0) ws.skip[blockIdx.x] = 1;
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void hess_vec(double* __restrict__ Hm, int N, 
     double vj = 0.0;
     if (j < i) vj = (j == ii ? hii : row[j]) / mx2 * 1.4142135623730951 / div;              // :51-52
     v[j] = vj;
+    if (vcol) vcol[(long)j * ws.nstore] = vj;
   }
   __syncthreads();
   for (int j = t; j < ii; j += 256) row[j] = 0.0;                                           // :83
@@ -189,6 +192,11 @@ __global__ __launch_bounds__(256) void hess_pass_b(double* __restrict__ Hm, doub
   for (int j = r0; j < r0 + HR && j < nrows; j++) H[(long)j * N + k] -= y[j] * vk + v[j] * wk;
 }
 
+__global__ void hess_fill(double* __restrict__ x, int n, double val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = val;
+}
+
 // U <- [[I, 0], [0, 1]] pattern of hessenberg.js:33 / :88-89 (identity; the reflectors never touch the last row/column)
 __global__ void hess_init_u(double* __restrict__ Um, int N) {
   const long base = (long)blockIdx.z * N * N;
@@ -213,20 +221,35 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
   const int Pmax = (N + HR - 1) / HR;
   Nd4WsScope scope(h);
   void* p = nullptr;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * ((size_t)4 * N + (size_t)Pmax * N) + sizeof(int) * (size_t)batch + 64, &p));
+  // one big matrix: U is not dragged through every step (its two passes are half of the traffic) but formed at the end
+  // from the stored reflectors, U = I - V T V^T (nd4_wy_form: Gram + level-wise T + two GEMMs; tau = 1 since v^T v = 2)
+  const bool wy = batch <= 4 && N >= 256;
+  const int nstore = wy ? ((N + 15) / 16) * 16 : 0;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)batch * ((size_t)4 * N + (size_t)Pmax * N + (size_t)N * nstore) + (size_t)nstore + 16) +
+                              sizeof(int) * (size_t)batch + 64, &p));
   HessWs ws;
   ws.v = static_cast<double*>(p); ws.y = ws.v + (size_t)batch * N; ws.yu = ws.y + (size_t)batch * N; ws.w = ws.yu + (size_t)batch * N;
   ws.xpart = ws.w + (size_t)batch * N;
-  ws.skip = reinterpret_cast<int*>(ws.xpart + (size_t)batch * Pmax * N);
+  ws.vstore = wy ? ws.xpart + (size_t)batch * Pmax * N : nullptr;
+  ws.nstore = nstore;
+  double* ones = ws.xpart + (size_t)batch * Pmax * N + (size_t)batch * N * nstore;
+  ws.skip = reinterpret_cast<int*>(ones + nstore + 16);
   ws.sV = N; ws.sX = (long)Pmax * N;
+  if (wy) {
+    ND4_HIP(hipMemsetAsync(ws.vstore, 0, sizeof(double) * (size_t)batch * N * nstore, h->stream));
+    hipLaunchKernelGGL(hess_fill, dim3((unsigned)((nstore + 255) / 256)), dim3(256), 0, h->stream, ones, nstore, 1.0);
+  }
   const int cchunks = (N + 255) / 256;
   for (int i = N - 1; i > 1; i--) {
     hipLaunchKernelGGL(hess_vec, dim3((unsigned)batch), dim3(256), 0, h->stream, H, N, i, ws);
     const unsigned rg = (unsigned)((N - 1 + HR - 1) / HR);           // row groups: enough for U's N-1 rows (H uses i <= N-1)
-    hipLaunchKernelGGL(hess_pass_a, dim3(rg, 2, (unsigned)batch), dim3(256), 0, h->stream, H, U, N, i, ws);
+    hipLaunchKernelGGL(hess_pass_a, dim3(rg, wy ? 1 : 2, (unsigned)batch), dim3(256), 0, h->stream, H, U, N, i, ws);
     hipLaunchKernelGGL(hess_reduce, dim3((unsigned)((N + RC - 1) / RC), (unsigned)batch), dim3(256), 0, h->stream, N, i, ws);
-    hipLaunchKernelGGL(hess_pass_b, dim3((unsigned)(2 * cchunks), rg, (unsigned)batch), dim3(256), 0, h->stream, H, U, N, i, cchunks, ws);
+    hipLaunchKernelGGL(hess_pass_b, dim3((unsigned)((wy ? 1 : 2) * cchunks), rg, (unsigned)batch), dim3(256), 0, h->stream, H, U, N, i, cchunks, ws);
     ND4_HIP(hipGetLastError());
   }
+  if (wy)
+    for (int m = 0; m < batch; m++)                                   // skipped steps stored v = 0: they drop out of V T V^T
+      ND4_TRY(nd4_wy_form(h, N, nstore, ws.vstore + (size_t)m * N * nstore, ones, 1, U + (size_t)m * nn, N));
   return 0;
 }

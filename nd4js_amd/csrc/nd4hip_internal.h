@@ -74,6 +74,7 @@ int nd4_getrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const doubl
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
 int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
                      double* R, long ldr, long sR, const double* taus, long sTau, int* flips);
+int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* Tdiag, int bs, double* Q, int Lq);
 int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R, bool full);
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);

@@ -548,51 +548,16 @@ int apply_block_reflector(nd4hip_handle* h, const QrWs& ws, int batch, int M, in
   return nd4_gemm(h, false, false, m, n, NB, -1.0, Vp, ws.ldv, ws.sV, ws.W2, ws.ldw, ws.sW2, 1.0, C0, ldc, strideC, batch);
 }
 
-// diagonal NB x NB blocks of the n x n compact-WY factor <- the panels' T factors (everything else zero)
-__global__ void qr_t_diag(const double* __restrict__ Tp, double* __restrict__ Tall, int n) {
-  const int pnl = blockIdx.x, t = threadIdx.x;                      // 256 threads = one NB x NB block
-  Tall[(long)(pnl * NB + t / NB) * n + pnl * NB + t % NB] = Tp[(long)pnl * NB * NB + t];
+// diagonal bs x bs blocks of the n x n compact-WY factor <- the given blocks (everything else zero); bs = 1: the taus
+__global__ void wy_t_diag(const double* __restrict__ Tp, double* __restrict__ Tall, int n, int bs) {
+  const int blk = blockIdx.x, t = threadIdx.x;                      // bs * bs threads
+  Tall[(long)(blk * bs + t / bs) * n + blk * bs + t % bs] = Tp[(long)blk * bs * bs + t];
 }
 
-// Q[:, 0:Lq] = (H_0 H_1 ... H_{p-1}) [I; 0] formed at once from the compact-WY representation of ALL reflectors:
-//   H_0 ... H_{p-1} = I - V T V^T,  T block upper triangular with the panels' T factors on its diagonal and
-//   T[1,2] = -T1 (V1^T V2) T2 for two adjacent groups (applied level by level: groups of 16, 32, 64, ... columns).
-// One Gram matrix V^T V (TN GEMM), log2(p) levels of two strided-batched small GEMMs, W = T V[0:Lq,:]^T and Q = E - V W:
-// ~20 launches and 6 M n^2 flop on the tiled MFMA kernel instead of 3 launches per panel (the backward loop of rank-16
-// block reflectors was 4.3 of the 13 ms of a 2048^2 factorisation, launch- and C-traffic-bound).
 int form_q_compact_wy(nd4hip_handle* h, const QrWs& ws, int batch, int M, int Lq, int npanels, double* Q, long sQ) {
   const int n = npanels * NB;                                       // == ws.ldv
-  Nd4WsScope scope(h);
-  void* p = nullptr;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)n * n * 2 + (size_t)n * n / 2 + (size_t)n * Lq + 64), &p));
-  double* G = static_cast<double*>(p);
-  double* Tall = G + (size_t)n * n;
-  double* tmp = Tall + (size_t)n * n;
-  double* W = tmp + (size_t)n * n / 2 + 16;
-  for (int m = 0; m < batch; m++) {
-    const double* V = ws.V + (long)m * ws.sV;
-    ND4_TRY(nd4_gemm(h, true, false, n, n, M, 1.0, V, n, 0, V, n, 0, 0.0, G, n, 0, 1));
-    ND4_HIP(hipMemsetAsync(Tall, 0, sizeof(double) * (size_t)n * n, h->stream));
-    hipLaunchKernelGGL(qr_t_diag, dim3((unsigned)npanels), dim3(NB * NB), 0, h->stream, ws.T + (long)m * ws.sT, Tall, n);
-    ND4_HIP(hipGetLastError());
-    for (int b = NB; b < n; b *= 2) {
-      const long step = 2l * b * (n + 1);                           // from one pair of groups to the next, along the diagonal
-      const int full = n / (2 * b);
-      if (full > 0) {
-        ND4_TRY(nd4_gemm(h, false, false, b, b, b, 1.0, G + b, n, step, Tall + (long)b * (n + 1), n, step, 0.0, tmp, b, (long)b * b, full));
-        ND4_TRY(nd4_gemm(h, false, false, b, b, b, -1.0, Tall, n, step, tmp, b, (long)b * b, 0.0, Tall + b, n, step, full));
-      }
-      const int i0 = full * 2 * b, n2 = n - i0 - b;                  // ragged last pair: second group narrower
-      if (n2 > 0) {
-        ND4_TRY(nd4_gemm(h, false, false, b, n2, n2, 1.0, G + (long)i0 * n + i0 + b, n, 0, Tall + (long)(i0 + b) * (n + 1), n, 0, 0.0, tmp, n2, 0, 1));
-        ND4_TRY(nd4_gemm(h, false, false, b, n2, b, -1.0, Tall + (long)i0 * (n + 1), n, 0, tmp, n2, 0, 0.0, Tall + (long)i0 * n + i0 + b, n, 0, 1));
-      }
-    }
-    ND4_TRY(nd4_gemm(h, false, true, n, Lq, n, 1.0, Tall, n, 0, V, n, 0, 0.0, W, Lq, 0, 1));                 // W = T V[0:Lq,:]^T
-    double* Qm = Q + (long)m * sQ;
-    ND4_TRY(nd4_set_identity(h, M, Lq, Qm, Lq, 1, sQ));
-    ND4_TRY(nd4_gemm(h, false, false, M, Lq, n, -1.0, V, n, 0, W, Lq, 0, 1.0, Qm, Lq, 0, 1));               // Q = E - V W
-  }
+  for (int m = 0; m < batch; m++)
+    ND4_TRY(nd4_wy_form(h, M, n, ws.V + (long)m * ws.sV, ws.T + (long)m * ws.sT, NB, Q + (long)m * sQ, Lq));
   return 0;
 }
 
@@ -733,4 +698,42 @@ int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool 
   }
   ND4_HIP(hipGetLastError());
   return 0;
+}
+
+// Q [M, Lq] (row-major, ld Lq) = (H_0 H_1 ... H_{n-1}) [I; 0] for reflectors H_j = I - tau_j v_j v_j^T given as the columns of
+// V [M, n] (ld n), formed at once from their compact-WY representation H_0 ... H_{n-1} = I - V T V^T: T is upper triangular
+// with the given bs x bs factors on its diagonal (bs = 1: the taus themselves) and T[1,2] = -T1 (V1^T V2) T2 for two adjacent
+// groups, applied level by level (groups of bs, 2 bs, 4 bs, ... columns). One Gram matrix V^T V (TN GEMM), two
+// strided-batched small GEMMs per level, W = T V[0:Lq,:]^T and Q = E - V W: ~20-30 launches and 6 M n^2 flop on the MFMA
+// kernels instead of a backward loop of rank-bs updates. n must be a multiple of bs; zero columns of V are harmless.
+int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* Tdiag, int bs, double* Q, int Lq) {
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)n * n * 2 + (size_t)n * n / 2 + (size_t)n * Lq + 64), &p));
+  double* G = static_cast<double*>(p);
+  double* Tall = G + (size_t)n * n;
+  double* tmp = Tall + (size_t)n * n;
+  double* W = tmp + (size_t)n * n / 2 + 16;
+  ND4_TRY(nd4_gemm(h, true, false, n, n, M, 1.0, V, n, 0, V, n, 0, 0.0, G, n, 0, 1));
+  ND4_HIP(hipMemsetAsync(Tall, 0, sizeof(double) * (size_t)n * n, h->stream));
+  hipLaunchKernelGGL(wy_t_diag, dim3((unsigned)(n / bs)), dim3((unsigned)(bs * bs)), 0, h->stream, Tdiag, Tall, n, bs);
+  ND4_HIP(hipGetLastError());
+  for (int b = bs; b < n; b *= 2) {
+    const long step = 2l * b * (n + 1);                             // from one pair of groups to the next, along the diagonal
+    const int full = n / (2 * b);
+    for (int f0 = 0; f0 < full; f0 += 32768) {                      // gridDim.y limit of the batched launch
+      const int nf = full - f0 < 32768 ? full - f0 : 32768;
+      const long o = f0 * step;
+      ND4_TRY(nd4_gemm(h, false, false, b, b, b, 1.0, G + b + o, n, step, Tall + (long)b * (n + 1) + o, n, step, 0.0, tmp, b, (long)b * b, nf));
+      ND4_TRY(nd4_gemm(h, false, false, b, b, b, -1.0, Tall + o, n, step, tmp, b, (long)b * b, 0.0, Tall + b + o, n, step, nf));
+    }
+    const int i0 = full * 2 * b, n2 = n - i0 - b;                    // ragged last pair: second group narrower
+    if (n2 > 0) {
+      ND4_TRY(nd4_gemm(h, false, false, b, n2, n2, 1.0, G + (long)i0 * n + i0 + b, n, 0, Tall + (long)(i0 + b) * (n + 1), n, 0, 0.0, tmp, n2, 0, 1));
+      ND4_TRY(nd4_gemm(h, false, false, b, n2, b, -1.0, Tall + (long)i0 * (n + 1), n, 0, tmp, n2, 0, 0.0, Tall + (long)i0 * n + i0 + b, n, 0, 1));
+    }
+  }
+  ND4_TRY(nd4_gemm(h, false, true, n, Lq, n, 1.0, Tall, n, 0, V, n, 0, 0.0, W, Lq, 0, 1));                   // W = T V[0:Lq,:]^T
+  ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, 1, (long)M * Lq));
+  return nd4_gemm(h, false, false, M, Lq, n, -1.0, V, n, 0, W, Lq, 0, 1.0, Q, Lq, 0, 1);                     // Q = E - V W
 }
