@@ -14,7 +14,8 @@
 //     normalisation, bidiag.js:123-136 / :183-195), positive leading minors of U's top block for M > N (the c >= 0
 //     normalisation of bidiag.js:49-61 preserves the sign of the pivot, exactly like qr.js:111-115).
 // Unblocked (BLAS-2): every step is two matrix-vector products and two rank-1 updates on the trailing block, bound by HBM;
-// U and V are accumulated afterwards by applying the stored reflectors backwards to the identity.
+// U and V are formed afterwards from the stored reflectors: at once from their compact-WY form (nd4_wy_form: one big matrix)
+// or by applying them backwards to the identity (batches of small matrices).
 #include "nd4hip_internal.h"
 
 namespace {
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(256) void bd_rank1(Blk b, const double* __restrict_
   for (int r = rg; r < rg + 16 && r < b.r1; r++) X[(long)r * b.ld + c] -= p[(long)r * ldp] * qc;
 }
 
+__global__ void bd_fill(double* __restrict__ x, int n, double val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = val;
+}
 __global__ void bd_set_identity(double* __restrict__ Xm, int rows, int cols) {
   const long base = (long)blockIdx.z * rows * cols;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +280,24 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     const unsigned gy = (unsigned)(K < 512 ? K : 512);
     hipLaunchKernelGGL(bd_extract, dim3((unsigned)((J + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, W, M, N, B, K, J);
   }
+  if (batch <= 4 && K >= 256) {
+    // one big matrix: U and V at once from the compact-WY form of the stored reflectors (nd4_wy_form, shared with QR):
+    // U = [I;0] - UL (T_L UL[0:K,:]^T) with the taus on T_L's diagonal; V^T[:, 0:J] = E_J - VR^T (T_R VR[:,0:J]) with
+    // tau = 2 for the unit vectors of the right reflectors (a skipped step stored v = 0 and drops out).
+    Nd4WsScope scope2(h);
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)N * K + (size_t)N * J + (size_t)K + 16), &q));
+    double* VRt = static_cast<double*>(q);                   // N x K: column k = v_k
+    double* Vt = VRt + (size_t)N * K;                        // N x J
+    double* twos = Vt + (size_t)N * J;
+    hipLaunchKernelGGL(bd_fill, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, h->stream, twos, K, 2.0);
+    for (int m = 0; m < batch; m++) {
+      ND4_TRY(nd4_wy_form(h, M, K, UL + (size_t)m * sUL, tauL + (size_t)m * K, 1, U + (size_t)m * M * K, K));
+      ND4_TRY(nd4_transpose(h, K, N, VR + (size_t)m * sVRm, N, VRt, K, 1, 0, 0));
+      ND4_TRY(nd4_wy_form(h, N, K, VRt, twos, 1, Vt, J));
+      ND4_TRY(nd4_transpose(h, N, J, Vt, J, V + (size_t)m * J * N, N, 1, 0, 0));
+    }
+  } else {
   // ---- U = H_0 ... H_{K-1} [I; 0]: reflectors applied backwards ----
   {
     const unsigned gy = (unsigned)(M < 512 ? M : 512);
@@ -293,6 +316,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     if (!(k + 1 < N - 1)) continue;
     Blk b{V, N, (long)J * N, k + 1, J, k + 1, N};
     ND4_TRY(reflect_right(h, batch, b, VR + (long)k * N, sVRm, flagR, K, k, ws));
+  }
   }
   ND4_HIP(hipGetLastError());
   // ---- the reference's sign convention on (columns of U, rows of B) ----
