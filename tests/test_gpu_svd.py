@@ -127,3 +127,30 @@ def test_c4_2048_against_reference(la, golden):
     for x, key in ((u, "U"), (v, "V")):
         got, val = np.abs(x.reshape(-1)[g[key + "idx"]]), np.abs(g[key + "val"])
         assert np.abs(got - val).max() <= 1e-8
+
+
+@pytest.mark.parametrize("shape", [(129, 129), (130, 130), (200, 200), (321, 321), (520, 520), (1000, 1000), (300, 200), (200, 300)])
+def test_padded_block_path(la, shape):
+    """N >= 128 that is not a multiple of 64 runs the block kernels on a zero-padded copy: same bounds as everywhere."""
+    a = rng.matrix(1300 + shape[0] + 3 * shape[1], *shape)
+    info = {}
+    u, sv, v = la.svd_decomp(a, info=info)
+    assert 1 <= info["sweeps"] <= 30
+    check_properties(a, u, sv, v)
+    assert np.abs(sv - np.linalg.svd(a, compute_uv=False)).max() <= 1e-12 * sv.max()
+
+
+def test_padded_block_path_structured(la):
+    """rank-deficient and structured inputs through the padded path (zero rows of the input and of the padding coexist)"""
+    N = 200
+    b = rng.matrix(1400, N, 60)
+    zero_rows = rng.matrix(1401, N, N)
+    zero_rows[50:90] = 0.0
+    zero_cols = rng.matrix(1402, N, N)
+    zero_cols[:, 10:70] = 0.0
+    for a in (np.zeros((N, N)), np.eye(N), b @ rng.matrix(1403, 60, N), zero_rows, zero_cols, np.diag(np.arange(N, 0, -1.0)) * 1e-150,
+              rng.matrix(1404, 3, 150, 150)):
+        u, sv, v = la.svd_decomp(a)
+        check_properties(a, u, sv, v)
+        ref = np.linalg.svd(a, compute_uv=False)
+        assert np.abs(sv - ref).max() <= 1e-12 * max(ref.max(), 1e-300)
