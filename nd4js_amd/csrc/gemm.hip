@@ -43,6 +43,8 @@ struct GemmArgs {
   double alpha, beta;
   int tiles_m, tiles_n;
   int lower;          // 1: skip tiles that lie entirely above the diagonal (symmetric rank-k updates)
+  int kchunk;         // > 0: split-K, blockIdx.z owns k in [z*kchunk, (z+1)*kchunk) and writes its raw partial to Cpart
+  double* Cpart;      //      [z][batch][M][N] (ld = N)
 };
 
 // ---- global -> register staging -------------------------------------------------------------
@@ -132,6 +134,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   const double* __restrict__ A = g.A + bz * g.sA;
   const double* __restrict__ B = g.B + bz * g.sB;
   double* __restrict__ C = g.C + bz * g.sC;
+  int kbeg = 0, kend = g.K;
+  long ldc = g.ldc;
+  double alpha = g.alpha, beta = g.beta;
+  if (g.kchunk > 0) {                                 // split-K: raw partial product of this k range
+    kbeg = blockIdx.z * g.kchunk; kend = min(g.K, kbeg + g.kchunk);
+    C = g.Cpart + ((long)blockIdx.z * gridDim.y + bz) * g.M * g.N;
+    ldc = g.N; alpha = 1.0; beta = 0.0;
+  }
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -145,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 
   d2 ra[4], rb[4];
   auto gload = [&](int k0) {
-    if (TA) load_kmaj<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, g.K, t); else load_row<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, g.K, t);
-    if (TB) load_row<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, g.K, t);  else load_kmaj<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, g.K, t);
+    if (TA) load_kmaj<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, kend, t); else load_row<VEC, FULL>(ra, A, g.lda, m0, g.M, k0, kend, t);
+    if (TB) load_row<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, kend, t);  else load_kmaj<VEC, FULL>(rb, B, g.ldb, n0, g.N, k0, kend, t);
   };
   auto sstore = [&](int buf) {
     double* sa = lds + buf * 2 * TILE; double* sb = sa + TILE;
@@ -154,14 +164,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
     if (TB) store_row(sb, rb, t);  else store_kmaj(sb, rb, t);
   };
 
-  const int nk = (g.K + BK - 1) / BK;
-  gload(0);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  gload(kbeg);
   sstore(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);          // in flight during the MFMAs below
+    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);   // in flight during the MFMAs below
     const double* sa = lds + cur * 2 * TILE;
     const double* sb = sa + TILE;
 #pragma unroll
@@ -192,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: lane holds C[row = (lane>>4) + 4r][col = lane&15] of each 16x16 tile ----
-  const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
       for (int r = 0; r < 4; r++) {
         const int row = m0 + wm + i * 16 + fk + 4 * r;
         if (FULL || (row < g.M && col < g.N)) {
-          double* c = C + (long)row * g.ldc + col;
+          double* c = C + (long)row * ldc + col;
           double v = alpha * acc[i][j][r];
           if (beta != 0.0) v += beta * *c;
           *c = v;
@@ -308,6 +317,20 @@ int launch_smallk(nd4hip_handle* h, GemmArgs g, int64_t batch) {
   return 0;
 }
 
+// C = alpha * sum_z part[z] + beta * C   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void dgemm_splitk_reduce(const double* __restrict__ part, int nsplit, long per_split, int M, int N,
+                                                            double alpha, double beta, double* __restrict__ Cm, long ldc, long sC) {
+  const long b = blockIdx.y;
+  const long e = blockIdx.x * 256l + threadIdx.x;
+  if (e >= (long)M * N) return;
+  double s = 0.0;
+  for (int z = 0; z < nsplit; z++) s += part[z * per_split + b * (long)M * N + e];
+  double* c = Cm + b * sC + (e / N) * ldc + e % N;
+  double v = alpha * s;
+  if (beta != 0.0) v += beta * *c;
+  *c = v;
+}
+
 // ND4HIP_GEMM_TILED=1 sends every product through the tiled kernel (A/B measurements of the rank-k kernel)
 bool nd4_gemm_force_tiled() {
   static const bool v = [] { const char* e = getenv("ND4HIP_GEMM_TILED"); return e && *e && *e != '0'; }();
@@ -316,7 +339,8 @@ bool nd4_gemm_force_tiled() {
 
 template <bool TA, bool TB>
 int launch(nd4hip_handle* h, const GemmArgs& g, bool vec, int64_t batch) {
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1), block(256, 1, 1);
+  const unsigned nsplit = g.kchunk > 0 ? (unsigned)((g.K + g.kchunk - 1) / g.kchunk) : 1u;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, nsplit), block(256, 1, 1);
   const bool full = vec && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && g.K > 0;
   if (full)     hipLaunchKernelGGL((dgemm_kernel<TA, TB, true, true>), grid, block, 0, h->stream, g);
   else if (vec) hipLaunchKernelGGL((dgemm_kernel<TA, TB, true, false>), grid, block, 0, h->stream, g);
@@ -337,18 +361,41 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.alpha = alpha; g.beta = beta; g.lower = 0;
+  g.alpha = alpha; g.beta = beta; g.lower = 0; g.kchunk = 0; g.Cpart = nullptr;
   g.tiles_m = (int)((M + BM - 1) / BM); g.tiles_n = (int)((N + BN - 1) / BN);
   ND4_CHECK_ARG((int64_t)g.tiles_m * g.tiles_n < (1ll << 31), "nd4_gemm: too many tiles");
   if (smallk_ok(g, transA) && !nd4_gemm_force_tiled()) return transB ? launch_smallk<true>(h, g, batch) : launch_smallk<false>(h, g, batch);
+  // few output tiles and a long K (tall-skinny products, Gram matrices, Q^T y): split K over blockIdx.z so that the chip is
+  // filled, then add the partials in a fixed order. (64 x 4096) x (4096 x 4096): 0.62 -> see DESIGN.md 4.1.
+  Nd4WsScope scope(h);
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
+  int nsplit = 1;
+  if (tiles < 128 && K >= 512) {
+    int64_t want = 384 / tiles;
+    if (want > K / 256) want = K / 256;
+    if (want > 32) want = 32;
+    if (want >= 2) {
+      int64_t kc = ((K + want - 1) / want + BK - 1) / BK * BK;
+      nsplit = (int)((K + kc - 1) / kc);
+      void* p = nullptr;
+      ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)nsplit * (size_t)batch * (size_t)M * (size_t)N, &p));
+      g.kchunk = (int)kc; g.Cpart = static_cast<double*>(p);
+    }
+  }
   auto even = [](int64_t v) { return (v & 1) == 0; };
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // 16-byte loads need: aligned bases, even row strides / batch strides, and an even extent along
   // the contiguous axis of each operand (so a 2-element chunk is never half out of range).
   const bool vec = al16(A) && al16(B) && even(lda) && even(ldb) && even(sA) && even(sB) &&
                    even(transA ? M : K) && even(transB ? K : N);
-  if (transA) return transB ? launch<true, true>(h, g, vec, batch) : launch<true, false>(h, g, vec, batch);
-  return transB ? launch<false, true>(h, g, vec, batch) : launch<false, false>(h, g, vec, batch);
+  if (transA) ND4_TRY((transB ? launch<true, true>(h, g, vec, batch) : launch<true, false>(h, g, vec, batch)));
+  else        ND4_TRY((transB ? launch<false, true>(h, g, vec, batch) : launch<false, false>(h, g, vec, batch)));
+  if (g.kchunk > 0) {
+    hipLaunchKernelGGL(dgemm_splitk_reduce, dim3((unsigned)((M * N + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                       g.Cpart, nsplit, (long)batch * M * N, (int)M, (int)N, alpha, beta, C, (long)ldc, (long)sC);
+    ND4_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 // C[lower tiles] = alpha * A A^T + beta * C for A [N, K] (row-major, lda): every 128x128 tile that touches the diagonal
@@ -366,7 +413,7 @@ int nd4_gemm_nt_lower(nd4hip_handle* h, int64_t N, int64_t K, double alpha, cons
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = (int)N; g.N = (int)N; g.K = (int)K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.alpha = alpha; g.beta = beta; g.lower = 1;
+  g.alpha = alpha; g.beta = beta; g.lower = 1; g.kchunk = 0; g.Cpart = nullptr;
   if (smallk_ok(g, false) && !nd4_gemm_force_tiled()) return launch_smallk<true>(h, g, batch);
   g.tiles_m = (int)((N + BM - 1) / BM); g.tiles_n = g.tiles_m;
   auto ok = [](const double* p, int64_t ld, int64_t st) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0 && (st & 1) == 0; };
