@@ -572,9 +572,48 @@ int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const dou
 //               (R_jj >= 0 wherever something was eliminated; det Q = +1 fixes the last row when M <= N). For M > N the
 //               trailing M-N columns of Q are an orthonormal completion (not unique; the reference's is the one its
 //               rotation order happens to produce) and rows N.. of R are zero.
+// Tall-skinny input (M > 2048 rows, M >= 4 N): TSQR. The rows are cut into blocks of <= 2048 (what the register-resident
+// panel kernel holds), all blocks are factorised in ONE batched call, the stacked R factors (nblk N x N) are factorised
+// again (recursively), and Q = blockwise Q1_b Q2_b is one strided-batched GEMM. A QR factorisation is unique up to the signs
+// of R's rows, so the reference's convention is imposed on the final pair by nd4_givens_signs, whatever the levels did.
+// Without it a 65536 x 32 panel would run on one workgroup through the global-memory fallback (31 ms instead of < 1 ms).
+static int geqrf_tsqr(nd4hip_handle* h, int batch, int M, int N, const double* A, double* Q, double* R) {
+  const int nblk = (M + 2047) / 2048;
+  int mb = (M + nblk - 1) / nblk;
+  mb = (mb + 1) & ~1;
+  const long Mp = (long)nblk * mb;
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  const size_t nAp = (size_t)batch * Mp * N, nR1 = (size_t)batch * nblk * N * N;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (2 * nAp + 2 * nR1 + (size_t)batch * Mp * N) + sizeof(int) * ((size_t)batch * N + 2) + 64, &p));
+  double* Ap = static_cast<double*>(p);
+  double* Q1 = Ap + nAp;
+  double* R1 = Q1 + nAp;                                               // per matrix: the nblk R factors stacked = (nblk N) x N
+  double* Q2 = R1 + nR1;
+  double* Qp = Q2 + nR1;
+  int* flips = reinterpret_cast<int*>(Qp + (size_t)batch * Mp * N);
+  if (Mp != M) ND4_HIP(hipMemsetAsync(Ap, 0, sizeof(double) * nAp, h->stream));
+  ND4_TRY(nd4_copy_matrix(h, M, N, A, N, Ap, N, batch, (long)M * N, Mp * N));
+  ND4_TRY(nd4_geqrf_q_ex(h, (int64_t)batch * nblk, mb, N, Ap, Q1, R1, false));
+  ND4_TRY(nd4_geqrf_q_ex(h, batch, (int64_t)nblk * N, N, R1, Q2, R, false));
+  double* Qdst = (Mp == M) ? Q : Qp;
+  ND4_TRY(nd4_gemm(h, false, false, mb, N, N, 1.0, Q1, N, (long)mb * N, Q2, N, (long)N * N, 0.0, Qdst, N, (long)mb * N, (int64_t)batch * nblk));
+  if (Mp != M) ND4_TRY(nd4_copy_matrix(h, M, N, Qp, N, Q, N, batch, Mp * N, (long)M * N));
+  return nd4_givens_signs(h, batch, M, N, N, true, Q, N, (long)M * N, R, N, (long)N * N, nullptr, 0, flips);
+}
+
 int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A, double* Q, double* R, bool full) {
   ND4_CHECK_ARG(M64 < (1ll << 30) && N64 < (1ll << 30) && batch64 < 65536, "nd4_geqrf_q: extent out of range");
   const int M = (int)M64, N = (int)N64, batch = (int)batch64;
+  {
+    static const bool tsqr_off = [] { const char* e = getenv("ND4HIP_QR_NO_TSQR"); return e && *e && *e != '0'; }();
+    const long nblk = (M + 2047) / 2048;
+    // every block needs >= N rows, and the stacked R (nblk N rows) must either fit the fast panel kernel directly or be
+    // at most half as tall as the input (so that the recursion terminates quickly)
+    if (!full && !tsqr_off && M > 2048 && N <= 2048 && (long)batch * nblk <= 32768 && M / nblk >= N &&
+        (nblk * N <= 2048 || 2 * nblk * N <= (long)M))
+      return geqrf_tsqr(h, batch, M, N, A, Q, R);
+  }
   const int L = M < N ? M : N;
   const int npanels = (L + NB - 1) / NB;
   const bool tall = M > N;

@@ -320,7 +320,8 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
 
 int nd4_gesvdj(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const double* A,
                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
-  ND4_CHECK_ARG(M64 < 46000 && N64 < 46000 && batch64 < 65536, "nd4_gesvdj: extent out of range");
+  ND4_CHECK_ARG((M64 < N64 ? M64 : N64) < 46000 && M64 < (1ll << 30) && N64 < (1ll << 30) && batch64 < 65536,
+                "nd4_gesvdj: extent out of range");              // the Jacobi part works on min(M,N)^2; QR takes the long side
   const int M = (int)M64, N = (int)N64, batch = (int)batch64;
   const int L = M < N ? M : N;
   Nd4WsScope scope(h);

@@ -201,3 +201,30 @@ def test_qr_decomp_inplace_rejects_like_reference():
         la.qr_decomp_inplace(np.ones((3, 2)), np.ones((4, 1)))
     with pytest.raises(TypeError):
         la.qr_decomp_inplace(np.ones((3, 2), dtype=np.float32), np.ones((3, 1)))
+
+
+# ---- tall-skinny input: TSQR (blocks of <= 2048 rows factorised in one batched call, stacked R factorised again) ----
+@pytest.mark.parametrize("shape", [(2049, 3), (4097, 64), (5000, 30), (20000, 7), (8192, 256), (10000, 1), (2, 3000, 16), (3000, 1000), (2500, 1200)])
+def test_tsqr_matches_reference_branch(la, shape):
+    a = rng.matrix(4500 + shape[-2] + shape[-1], *shape)
+    q, r = la.qr_decomp(a)
+    check_properties(a, q, r)
+    if shape[-2] * shape[-1] ** 2 <= 4e8:                 # the Givens oracle costs M N^2
+        rq, rr = oracle.qr_decomp(a)
+        assert relerr(r, rr) <= 1e-11 and relerr(q, rq) <= 1e-11
+    # the c >= 0 convention: every leading principal minor of Q's top block is positive
+    N = shape[-1]
+    top = q[..., :N, :]
+    for k in range(1, min(N, 24) + 1):
+        assert np.all(np.linalg.det(top[..., :k, :k]) > 0)
+
+
+def test_tsqr_lstsq_and_svd_chain(la):
+    a = rng.matrix(4600, 30000, 20)
+    y = rng.matrix(4601, 30000, 3)
+    x = la.qr_lstsq(la.qr_decomp(a), y)
+    assert relerr(x, np.linalg.lstsq(a, y, rcond=None)[0]) <= 1e-11
+    b = rng.matrix(4602, 50000, 12)                        # longer than the Jacobi part could take on its own
+    u, sv, v = la.svd_decomp(b)
+    assert np.abs(sv - np.linalg.svd(b, compute_uv=False)).max() <= 1e-12 * sv.max()
+    assert np.linalg.norm((u * sv) @ v - b) <= 1e-12 * np.linalg.norm(b) and np.abs(u.T @ u - np.eye(12)).max() <= 1e-13
