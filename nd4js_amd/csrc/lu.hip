@@ -215,6 +215,122 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
   }
 }
 
+// The same kernel for taller panels: T = 1024 threads leave 128 VGPRs per lane, enough for R = 4 rows of W = 8 columns:
+// 2048 < m <= 4096 rows are factorised 8 columns at a time instead of falling back to the global-memory panel.
+template <int R, int W, int T>
+__global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
+  __shared__ PivCand s_red[T / 64];
+  __shared__ double s_u[W], s_j[W];
+  double* A = LU + blockIdx.x * strideM;
+  int32_t* ip = ipiv + (long)blockIdx.x * N;
+  const int t = threadIdx.x, wave = t >> 6;
+  double a[R][W];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + T * i;
+#pragma unroll
+    for (int c = 0; c < W; c++) a[i][c] = 0.0;
+    if (r < N) {
+      const double* src = A + (long)r * N + j0;
+      if (nb == W && (N & 1) == 0) {                    // 16-byte loads: each lane reads its own 128-B row segment
+#pragma unroll
+        for (int c = 0; c < W; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) if (c < nb) a[i][c] = src[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    if (k < nb) {                                        // uniform
+      const int jc = j0 + k;
+      // ---- arg-max of |column k| over rows >= jc ----
+      PivCand cand{-2.0, 0x7fffffff};
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + T * i;
+        PivCand o{pivot_mag(a[i][k], r, jc), r};
+        if (r < jc || r >= N) o.mag = -2.0;
+        cand = better(cand, o);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        PivCand o;
+        o.mag = __shfl_xor(cand.mag, off);
+        o.idx = __shfl_xor(cand.idx, off);
+        cand = better(cand, o);
+      }
+      if ((t & 63) == 0) s_red[wave] = cand;
+      __syncthreads();
+      PivCand best = s_red[0];
+#pragma unroll
+      for (int w = 1; w < T / 64; w++) best = better(best, s_red[w]);
+      const int piv = nopivot ? jc : best.idx;
+      if (t == 0) {
+        ip[jc] = piv;
+        }
+      // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
+      const int pt = (piv - j0) % T, pi = (piv - j0) / T;
+      if (t == pt) {
+#pragma unroll
+        for (int i = 0; i < R; i++)
+          if (i == pi) {
+#pragma unroll
+            for (int c = 0; c < W; c++) s_u[c] = a[i][c];
+          }
+      }
+      if (t == k) {
+#pragma unroll
+        for (int c = 0; c < W; c++) s_j[c] = a[0][c];
+      }
+      __syncthreads();
+      if (piv != jc) {
+        if (t == pt) {
+#pragma unroll
+          for (int i = 0; i < R; i++)
+            if (i == pi) {
+#pragma unroll
+              for (int c = 0; c < W; c++) a[i][c] = s_j[c];
+            }
+        }
+        if (t == k) {
+#pragma unroll
+          for (int c = 0; c < W; c++) a[0][c] = s_u[c];
+        }
+      }
+      // ---- eliminate below the pivot ----
+      const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + T * i;
+        if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
+          const double l = a[i][k] / u[k];               // lu.js:68
+          a[i][k] = l;
+#pragma unroll
+          for (int c = k + 1; c < W; c++) a[i][c] -= l * u[c];   // lu.js:71-72
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // keep the unrolled columns from interleaving (VGPR pressure)
+  }
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + T * i;
+    if (r < N) {
+      double* dst = A + (long)r * N + j0;
+      if (nb == W && (N & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < W; c += 2) *reinterpret_cast<double2*>(dst + c) = double2{a[i][c], a[i][c + 1]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) if (c < nb) dst[c] = a[i][c];
+      }
+    }
+  }
+}
+
 // ---- fast panel kernel: the panel (m <= 64*RMAX rows x 16 cols) lives in registers -------------
 // lane group g (16 lanes) owns rows j0 + g + 64*i; lane c of the group owns column j0 + c.
 template <int R>
@@ -379,6 +495,11 @@ void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0,
 
 }  // namespace
 
+template <int R, int W, int T>
+void launch_panel_row_wt(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
+  hipLaunchKernelGGL((lu_panel_row_wt<R, W, T>), dim3(batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+}
+
 static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, double* LU, int32_t* P, int nopivot) {
   ND4_CHECK_ARG(N64 < (1ll << 30) && batch < 65536, "nd4_getrf: extent out of range");
   const int N = (int)N64;
@@ -390,10 +511,15 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   ND4_TRY(nd4_ws_alloc(h, sizeof(int32_t) * total, &ws));
   int32_t* ipiv = static_cast<int32_t*>(ws);
 
-  for (int j0 = 0; j0 < N; j0 += NB) {
-    const int nb = N - j0 < NB ? N - j0 : NB;
+  static const bool tall8_off = [] { const char* e = getenv("ND4HIP_LU_NO_TALL8"); return e && *e && *e != '0'; }();
+  for (int j0 = 0, step = NB; j0 < N; j0 += step) {
     const int m = N - j0;
-    if (m >= 64 && m <= 2048) {
+    const bool tall8 = !tall8_off && m > 2048 && m <= 4096;          // 8-column panels, 1024 threads x 4 rows x 8 columns
+    step = tall8 ? 8 : NB;
+    const int nb = N - j0 < step ? N - j0 : step;
+    if (tall8) {
+      launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+    } else if (m >= 64 && m <= 2048) {
       if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
       else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
       else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);

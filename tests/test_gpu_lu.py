@@ -85,12 +85,16 @@ def test_int32_input_is_promoted(la):
     assert lu.dtype == np.float64 and np.array_equal(p, rp) and relerr(lu, rlu) <= 1e-12
 
 
-def test_beyond_register_panel(la):
-    """N > 3072: the first panels run the global-memory panel kernel."""
-    N = 3200
+@pytest.mark.parametrize("N", [2049, 2100, 3200, 4096, 4200])
+def test_beyond_register_panel(la, N):
+    """2048 < m <= 4096: 8-column panels on 1024 threads; N > 4096: the first panels run the global-memory panel kernel."""
+    import scipy.linalg
     a = rng.matrix(804, N, N)
     lu, p = la.lu_decomp(a)
     check_properties(a, lu, p)
+    pl, ll, ul = scipy.linalg.lu(a, p_indices=True)       # A = L[pl] U; LAPACK picks the same pivots on generic input (SURVEY.md 8a A5)
+    assert np.array_equal(p, np.argsort(pl))
+    assert relerr(np.triu(lu), ul) <= 1e-11 and relerr(np.tril(lu, -1), np.tril(ll, -1)) <= 1e-11
 
 
 def test_c3_2048_against_reference(la, golden):
