@@ -514,11 +514,16 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   static const bool tall8_off = [] { const char* e = getenv("ND4HIP_LU_NO_TALL8"); return e && *e && *e != '0'; }();
   for (int j0 = 0, step = NB; j0 < N; j0 += step) {
     const int m = N - j0;
-    const bool tall8 = !tall8_off && m > 2048 && m <= 4096;          // 8-column panels, 1024 threads x 4 rows x 8 columns
-    step = tall8 ? 8 : NB;
+    // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
+    // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
+    const bool tall8 = !tall8_off && m > 2048 && m <= 4096;
+    const bool tall4 = !tall8_off && m > 4096 && m <= 8192;
+    step = tall8 ? 8 : tall4 ? 4 : NB;
     const int nb = N - j0 < step ? N - j0 : step;
     if (tall8) {
       launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+    } else if (tall4) {
+      launch_panel_row_wt<8, 4, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
     } else if (m >= 64 && m <= 2048) {
       if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
       else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);

@@ -85,9 +85,9 @@ def test_int32_input_is_promoted(la):
     assert lu.dtype == np.float64 and np.array_equal(p, rp) and relerr(lu, rlu) <= 1e-12
 
 
-@pytest.mark.parametrize("N", [2049, 2100, 3200, 4096, 4200])
+@pytest.mark.parametrize("N", [2049, 2100, 3200, 4096, 4200, 6000])
 def test_beyond_register_panel(la, N):
-    """2048 < m <= 4096: 8-column panels on 1024 threads; N > 4096: the first panels run the global-memory panel kernel."""
+    """2048 < m <= 4096: 8-column panels on 1024 threads; up to 8192: 4-column panels; beyond: the global-memory panel kernel."""
     import scipy.linalg
     a = rng.matrix(804, N, N)
     lu, p = la.lu_decomp(a)
