@@ -368,6 +368,175 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   }
 }
 
+// ---- the same panel kernel for 2048 < m <= 4096 rows: 1024 threads leave 128 VGPRs per lane = R = 4 rows of EIGHT columns.
+// A 16-column panel slot is then factorised in two halves (half = 0 / 1, columns c0 = j0 + 8 half): half 0 writes T[0:8,0:8]
+// and zeroes the rest of the slot, so that the ordinary block-reflector machinery can apply (v_0..v_7) to columns 8..15
+// while V[:, 8:16] is still zero; half 1 writes T[8:16,8:16]; qr_t12_finish completes T[0:8,8:16] = -T11 (V1^T V2) T22.
+template <int R>
+__global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                     double* __restrict__ Vall, long ldv, long strideV,
+                                                     double* __restrict__ Tall, long strideT,
+                                                     double* __restrict__ taus, long strideTau, int c0, int nb) {
+  constexpr int W8 = 8, NW = 16;                       // columns of this kernel, waves per workgroup
+  __shared__ double s_red[NW];
+  __shared__ double s_w[NW][W8];
+  __shared__ double s_T[W8][W8 + 1];
+  __shared__ double s_Z[W8][W8];
+  __shared__ double s_tau[W8];
+  const int j0 = c0;                                   // rows and columns of this half start at its own diagonal
+  __shared__ double s_alpha;
+  double* A = Wm + blockIdx.x * strideW;
+  double* V = Vall + blockIdx.x * strideV;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  const int mycol = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);                   // column this lane ends up with
+
+  double a[R][W8];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + 1024 * i;
+#pragma unroll
+    for (int c = 0; c < W8; c++) a[i][c] = 0.0;
+    if (r < M) {
+      const double* src = A + (long)r * ld + j0;
+      if (nb == W8 && (ld & 1) == 0) {                   // 16-byte loads of the lane's own 128-B row segment
+#pragma unroll
+        for (int c = 0; c < W8; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < nb) a[i][c] = src[c];
+      }
+    }
+  }
+  if (t < W8 * (W8 + 1)) (&s_T[0][0])[t] = 0.0;
+
+  // one column step per compile-time k (generic lambda, see lu.hip: convergent DPP ops block `#pragma unroll`)
+  auto column_step = [&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if (k < nb) {
+      const int jc = j0 + k;
+      double part = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        if (r > jc) part += a[i][k] * a[i][k];
+      }
+      if (t == k) s_alpha = a[0][k];
+      part = nd4dpp::wave_sum(part);
+      if (lane == 0) s_red[wave] = part;
+      __syncthreads();
+      double sigma = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) sigma += s_red[w];
+      const double alpha = s_alpha;
+      double beta = alpha, tau = 0.0, scale = 0.0;
+      if (sigma != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      double vr[R], d[W8];
+#pragma unroll
+      for (int c = 0; c < W8; c++) d[c] = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+#pragma unroll
+        for (int c = 0; c < W8; c++) d[c] += vr[i] * a[i][c];
+      }
+      // halving butterfly over the 8 lanes of a group (4 + 2 + 1 exchanges), then across the 8 groups of the wave
+      double e4[4], e2[2], e1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const double snd = b0 ? d[j] : d[j + 4], kp = b0 ? d[j + 4] : d[j]; e4[j] = kp + nd4dpp::xor1(snd); }
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const double snd = b1 ? e4[j] : e4[j + 2], kp = b1 ? e4[j + 2] : e4[j]; e2[j] = kp + nd4dpp::xor2(snd); }
+      { const double snd = b2 ? e2[0] : e2[1], kp = b2 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor4(snd); }
+      e1 += nd4dpp::xor8(e1);
+      e1 += __shfl_xor(e1, 16);
+      e1 += __shfl_xor(e1, 32);
+      if (lane < W8) s_w[wave][mycol] = e1;
+      __syncthreads();
+      double tot = 0.0;                                   // lane -> column lane & 7
+#pragma unroll
+      for (int w = 0; w < NW; w++) tot += s_w[w][lane & 7];
+      double wv[W8];                                      // wave-uniform totals
+#define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
+      ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3) ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7)
+#undef ND4_RL
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        const double tv = tau * vr[i];
+#pragma unroll
+        for (int c = k + 1; c < W8; c++) a[i][c] -= tv * wv[c];
+        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < k) s_Z[k][c] = wv[c];
+        s_tau[k] = tau;
+        taus[blockIdx.x * strideTau + j0 + k] = tau;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define ND4_STEP(K) column_step(std::integral_constant<int, K>{});
+  ND4_STEP(0) ND4_STEP(1) ND4_STEP(2) ND4_STEP(3) ND4_STEP(4) ND4_STEP(5) ND4_STEP(6) ND4_STEP(7)
+#undef ND4_STEP
+  __syncthreads();
+  if (t < nb) {                                          // larft: row t of T depends only on row t
+    double row[W8];
+#pragma unroll
+    for (int k = 0; k < W8; k++) row[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W8; k++) {
+      if (k == t) row[k] = s_tau[k];
+      else if (k > t && k < nb) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < W8; j++) if (j >= t && j < k) sum += row[j] * s_Z[k][j];
+        row[k] = -s_tau[k] * sum;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W8; k++) s_T[t][k] = row[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int lr = t + 1024 * i, r = j0 + lr;
+    if (r < M) {
+      double* w = A + (long)r * ld + j0;
+      double* v = V + (long)r * ldv + j0;
+      double wv[W8], vv[W8];
+#pragma unroll
+      for (int c = 0; c < W8; c++) {
+        wv[c] = (lr <= c) ? a[i][c] : 0.0;                       // R part (upper triangle incl. diagonal)
+        vv[c] = (lr < c) ? 0.0 : ((lr == c) ? 1.0 : a[i][c]);    // explicit reflector: zeros above, unit diagonal
+      }
+      if (nb == W8 && (ld & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < W8; c += 2) {
+          *reinterpret_cast<double2*>(w + c) = double2{wv[c], wv[c + 1]};
+          *reinterpret_cast<double2*>(v + c) = double2{vv[c], vv[c + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < nb) { w[c] = wv[c]; v[c] = vv[c]; }
+      }
+    }
+  }
+  if (t < 16 * 16) {                                     // the 16 x 16 slot of the enclosing panel
+    const int slot0 = (c0 / 16) * 16, half = (c0 - slot0) / 8;
+    const int i = t / 16, j = t % 16;
+    double* Ts = Tall + blockIdx.x * strideT + (long)(slot0 / 16) * 256;
+    const bool mine = (i / 8 == half) && (j / 8 == half);
+    if (mine) Ts[t] = ((i & 7) <= (j & 7) && (j & 7) < nb) ? s_T[i & 7][j & 7] : 0.0;
+    else if (half == 0) Ts[t] = 0.0;
+  }
+}
+
 // ------------------------------------------------------------------------------------ V^T C
 // Wp[chunk][i][j] = sum_{r in chunk} V[r][i] * C[r][j]; V: m x 16 (ldv), C: m x n (ldc).
 // grid (ceil(n/64), ceil(m/256), batch), 256 threads: wave w takes rows chunk*256 + w*64 .. +64 and
@@ -488,6 +657,26 @@ __global__ void qr_flip_cols(double* __restrict__ X, long ld, long strideX, int 
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= cols || !flips[col]) return;
   for (int r = blockIdx.y; r < rows; r += gridDim.y) X[(long)r * ld + col] = -X[(long)r * ld + col];
+}
+
+// T[0:8, 8:16] = -T11 (V1^T V2) T22 for a 16-column slot factorised in two halves; G = V1^T V2 (8 x 8, row-major)
+__global__ __launch_bounds__(64) void qr_t12_finish(double* __restrict__ Tall, long strideT, int panel, const double* __restrict__ Gm, long sG) {
+  __shared__ double s_t[16][17], s_g[8][9], s_x[8][9];
+  double* T = Tall + blockIdx.x * strideT + (long)panel * 256;
+  const double* G = Gm + blockIdx.x * sG;
+  const int t = threadIdx.x, i = t / 8, j = t % 8;
+  for (int e = t; e < 256; e += 64) s_t[e / 16][e % 16] = T[e];
+  s_g[i][j] = G[t];
+  __syncthreads();
+  double x = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) x += s_g[i][q] * s_t[8 + q][8 + j];       // G T22
+  s_x[i][j] = x;
+  __syncthreads();
+  double y = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) y += s_t[i][q] * s_x[q][j];               // T11 (G T22)
+  T[i * 16 + 8 + j] = -y;
 }
 
 template <int R>
@@ -663,6 +852,24 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   for (int pnl = 0; pnl < npanels; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
     const int Rn = (m + 63) / 64;
+    static const bool tall8_off = [] { const char* e = getenv("ND4HIP_QR_NO_TALL8"); return e && *e && *e != '0'; }();
+    if (!tall8_off && m > 2048 && m <= 4096) {
+      // two 8-column halves on 1024 threads (qr_panel_row8): half 0, its reflectors applied to the other 8 columns, half 1,
+      // then T12 = -T11 (V1^T V2) T22 from one small split-K Gram product
+      const int nb1 = nb < 8 ? nb : 8;
+      hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb1);
+      ND4_HIP(hipGetLastError());
+      if (nb > 8) {
+        ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + 8, ld, sW, nb - 8));
+        hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau,
+                           j0 + 8, nb - 8);
+        ND4_HIP(hipGetLastError());
+        const double* V1 = ws.V + (long)j0 * ws.ldv + j0;
+        ND4_TRY(nd4_gemm(h, true, false, 8, 8, m, 1.0, V1, ws.ldv, ws.sV, V1 + 8, ws.ldv, ws.sV, 0.0, ws.W2, 8, ws.sW2, batch));
+        hipLaunchKernelGGL(qr_t12_finish, dim3(batch), dim3(64), 0, h->stream, ws.T, ws.sT, pnl, ws.W2, ws.sW2);
+        ND4_HIP(hipGetLastError());
+      }
+    } else
     if (m <= 512)       launch_panel_row<1>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (m <= 1024) launch_panel_row<2>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (m <= 2048) launch_panel_row<4>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);

@@ -228,3 +228,27 @@ def test_tsqr_lstsq_and_svd_chain(la):
     u, sv, v = la.svd_decomp(b)
     assert np.abs(sv - np.linalg.svd(b, compute_uv=False)).max() <= 1e-12 * sv.max()
     assert np.linalg.norm((u * sv) @ v - b) <= 1e-12 * np.linalg.norm(b) and np.abs(u.T @ u - np.eye(12)).max() <= 1e-13
+
+
+@pytest.mark.parametrize("shape", [(2100, 2100), (2049, 2056), (3000, 3000), (4096, 4096), (2, 2200, 2200), (3000, 2500)])
+def test_two_half_panels_beyond_2048_rows(la, shape):
+    """2048 < m <= 4096 rows: every 16-column panel is factorised as two 8-column halves on 1024 threads."""
+    a = rng.matrix(4700 + shape[-2], *shape)
+    q, r = la.qr_decomp(a)
+    check_properties(a, q, r)
+    M, N = shape[-2:]
+    qn, rn = np.linalg.qr(a)                                  # LAPACK, then the reference's sign convention
+    d = np.sign(np.diagonal(rn, axis1=-2, axis2=-1)).copy()
+    if M <= N:                                                # Givens-full: R_jj >= 0, det Q = +1 decides the last row
+        qq = qn * d[..., None, :]
+        d[..., -1] *= np.sign(np.linalg.det(qq))
+        assert np.all(np.diagonal(r, axis1=-2, axis2=-1)[..., :-1] >= 0) and np.allclose(np.linalg.det(q), 1.0)
+    else:                                                     # tall: positive leading minors of Q's top block
+        top = (qn * d[..., None, :])[..., :N, :]
+        import scipy.linalg
+        lu_nopiv = top.copy()                                 # unpivoted elimination: only the pivot signs matter
+        for k in range(N):
+            d[..., k] *= np.sign(lu_nopiv[..., k, k])
+            lu_nopiv[..., k + 1:, :] -= (lu_nopiv[..., k + 1:, k:k + 1] / lu_nopiv[..., k:k + 1, k:k + 1]) * lu_nopiv[..., k:k + 1, :]
+    rr, qr_ = rn * d[..., :, None], qn * d[..., None, :]
+    assert relerr(r, rr) <= 1e-11 and relerr(q, qr_) <= 1e-11
