@@ -221,13 +221,13 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   Nd4WsScope scope(h);
   const long sM = (long)N * N;
   void* p = nullptr;
-  // Block Jacobi on the matrix cores (svd_block.hip) wants N = 0 mod 64. Other N >= 128 run it on the matrix padded with
+  // Block Jacobi on the matrix cores (svd_block.hip) wants N = 0 mod 64. Other N >= 16 run it on the matrix padded with
   // zero rows and columns to Np = the next multiple of 64: a zero row has norm 0 < the noise floor and is never rotated, a
   // zero column stays zero under row rotations, so the leading N x N parts of W and Ut evolve exactly as they would alone
   // (Ut' = diag(Ut, I)) and are copied back before the epilogue. (The row-pair kernel it replaces there is 4-6x slower:
   // N = 1000 took 222 ms against 39 ms at 1024.)
   const bool noblock = getenv("ND4HIP_SVD_NOBLOCK") != nullptr;
-  const bool blocked = N >= 128 && !noblock;
+  const bool blocked = N >= 16 && !noblock;      // below 16 the row-pair kernel is fine (a few microseconds per matrix)
   const int Np = blocked ? ((N + 63) / 64) * 64 : N;
   const bool padded = Np != N;
   const long sMp = (long)Np * Np;
