@@ -107,3 +107,11 @@ def test_c3_2048_against_reference(la, golden):
     assert np.linalg.norm(got - val) / np.linalg.norm(val) <= 1e-11
     assert abs(np.linalg.norm(lu) - g.froLU) <= 1e-11 * g.froLU
     check_properties(a, lu, p)
+
+
+def test_tall_panels_batched(la):
+    """8-column panels with a batch: one workgroup of 1024 threads per matrix"""
+    a = rng.matrix(806, 2, 2100, 2100)
+    lu, p = la.lu_decomp(a)
+    check_properties(a, lu, p)
+    assert not np.array_equal(p[0], p[1])

@@ -146,3 +146,27 @@ def test_c2_4096_against_reference_samples(dev, golden):
     # size-independent property at full size: linearity  (A)(2B) == 2(AB) exactly (power of two)
     C2 = dev.matmul2(A, B * 2.0)
     assert torch.equal(C2, C * 2.0)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 200, 4096), (130, 70, 2001), (16, 16, 5000), (300, 300, 700)])
+def test_split_k_products(dev, ta, tb, M, N, K):
+    """few output tiles and a long K: K is split over blockIdx.z and the partials are added in a fixed order"""
+    import torch
+    A = rng.matrix(610, K, M) if ta else rng.matrix(610, M, K)
+    B = rng.matrix(611, N, K) if tb else rng.matrix(611, K, N)
+    C0 = rng.matrix(612, M, N)
+    ref = -1.25 * ((A.T if ta else A) @ (B.T if tb else B)) + 0.5 * C0
+    dA, dB, dC = (torch.from_numpy(x).cuda() for x in (A, B, C0))
+    dev.gemm_ex(ta, tb, -1.25, dA, dB, 0.5, dC, M, N, K, A.shape[1], B.shape[1], N)
+    out = dC.cpu().numpy()
+    assert relerr(out, ref) <= 1e-13
+    dC2 = torch.from_numpy(C0).cuda()                      # deterministic: same bits on a second run
+    dev.gemm_ex(ta, tb, -1.25, dA, dB, 0.5, dC2, M, N, K, A.shape[1], B.shape[1], N)
+    assert np.array_equal(dC2.cpu().numpy(), out)
+
+
+def test_split_k_batched_matmul2(la):
+    a, b = rng.matrix(620, 3, 100, 2000), rng.matrix(621, 2000, 60)      # 3 tiles in total, K = 2000
+    c = la.matmul2(a, b)
+    assert relerr(c, a @ b) <= 1e-13
