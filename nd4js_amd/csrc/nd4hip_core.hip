@@ -50,6 +50,7 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (auto& b : h->ws) (void)hipFree(b.p);
+  for (auto& b : h->stage) (void)hipFree(b.p);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

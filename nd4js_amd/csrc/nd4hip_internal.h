@@ -9,11 +9,15 @@
 
 struct Nd4WsBlock { char* p; size_t size, used; };
 
+struct Nd4Stage { void* p; size_t bytes; bool in_use; };   // cached device staging block of the host-pointer entry points
+
 struct nd4hip_handle {
   int device = 0;
   hipStream_t own_stream = nullptr;   // created by nd4hip_create
   hipStream_t stream = nullptr;       // the stream work is enqueued on (own or caller's)
   std::vector<Nd4WsBlock> ws;         // device workspace arena (bump allocation, LIFO release)
+  std::vector<Nd4Stage> stage;        // staging blocks kept between host-pointer calls (hipMalloc/hipFree cost ~100 us each)
+  size_t stage_bytes = 0;
   void* pinned = nullptr;             // small pinned host buffer for scalar read-backs
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -282,9 +282,14 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       }
       hipLaunchKernelGGL(jac_sweep_end, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, st, batch, active);
       ND4_HIP(hipGetLastError());
+      sweeps++;
+      // The convergence flag is read back (one stream synchronisation) after every sweep for large matrices; a sweep of a
+      // small matrix costs less than the round trip, so it is checked every 4th (N <= 64) / 2nd (N <= 256) sweep only:
+      // converged matrices are skipped on the device anyway (JacState.done), an extra sweep over them rotates nothing.
+      const int check_every = Np <= 64 ? 4 : (Np <= 256 ? 2 : 1);
+      if (sweeps % check_every != 0 && sweeps < MAX_SWEEPS) continue;
       ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
       ND4_HIP(hipStreamSynchronize(h->stream));
-      sweeps++;
       if (getenv("ND4HIP_SVD_DEBUG")) {
         double r; unsigned long long bb = *h_off; memcpy(&r, &bb, 8);
         fprintf(stderr, "[nd4hip svd] sweep %d: active matrices %u, max |cos| rotated %.3e\n", sweeps, h_active[0], sqrt(r));
