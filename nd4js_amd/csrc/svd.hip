@@ -145,6 +145,17 @@ __global__ __launch_bounds__(256) void jac_emit(const double* __restrict__ Wm, c
   if (t == 0) sv[(long)mat * N + r] = s;
 }
 
+// number of leading singular values above the noise floor (sv is sorted): rows z0.. of V need a completion
+__global__ void jac_count_rank(const double* __restrict__ svm, int N, const double* __restrict__ floor2, int* __restrict__ z0, int batch) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= batch) return;
+  const double* sv = svm + (long)m * N;
+  const double fl = floor2[m];
+  int z = N;
+  while (z > 0 && sv[z - 1] * sv[z - 1] <= fl) z--;
+  z0[m] = z;
+}
+
 // Rows of V whose singular value is at or below the noise floor (sorted to the end) are replaced by an orthonormal
 // completion: pick the unit vector e_j with the largest residual against the rows above, orthogonalise
 // twice (classical Gram-Schmidt with re-orthogonalisation), normalise. One workgroup per matrix.
@@ -250,7 +261,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   unsigned* active = reinterpret_cast<unsigned*>(st + batch);           // [1] + padding
   unsigned long long* offmax = reinterpret_cast<unsigned long long*>(active + 2);
   void* pin = nullptr;
-  ND4_TRY(nd4_pinned(h, 64, &pin));
+  ND4_TRY(nd4_pinned(h, 64 + sizeof(int) * (size_t)batch, &pin));
   unsigned* h_active = static_cast<unsigned*>(pin);
   unsigned long long* h_off = reinterpret_cast<unsigned long long*>(h_active + 2);
 
@@ -308,8 +319,36 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
   hipLaunchKernelGGL(jac_rank, dim3((unsigned)((N + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, svr, N, rank);
   hipLaunchKernelGGL(jac_emit, dim3((unsigned)N, (unsigned)batch), dim3(256), 0, h->stream, W, Ut, N, sM, svr, rank, V, Utp, sv);
-  hipLaunchKernelGGL(jac_complete, dim3((unsigned)batch), dim3(1024), 0, h->stream, V, N, sM, sv, floor2, scratch);
-  ND4_HIP(hipGetLastError());
+  if (N < 128) {
+    hipLaunchKernelGGL(jac_complete, dim3((unsigned)batch), dim3(1024), 0, h->stream, V, N, sM, sv, floor2, scratch);
+    ND4_HIP(hipGetLastError());
+  } else {
+    // Rank-deficient input: the rows of V that belong to singular values at the noise floor are an arbitrary orthonormal
+    // completion (the reference's are whatever its D&C leaves there). jac_complete builds them one by one on a single
+    // workgroup (N^3 work: 5.5 s for a rank-1 2048^2 matrix); here they come from ONE full QR of the r valid right vectors:
+    // qr_decomp_full(V[0:r,:]^T) = [+-V_r^T | Q2], and the rows of Q2^T are the completion.
+    int* z0d = reinterpret_cast<int*>(scratch);                       // scratch: batch * N doubles, idle here
+    int* z0h = reinterpret_cast<int*>(static_cast<char*>(pin) + 64);
+    hipLaunchKernelGGL(jac_count_rank, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, sv, N, floor2, z0d, batch);
+    ND4_HIP(hipGetLastError());
+    ND4_HIP(hipMemcpyAsync(z0h, z0d, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
+    ND4_HIP(hipStreamSynchronize(h->stream));
+    for (int m = 0; m < batch; m++) {
+      const int r = z0h[m];
+      if (r >= N) continue;
+      double* Vm = V + (size_t)m * sM;
+      if (r == 0) { ND4_TRY(nd4_set_identity(h, N, N, Vm, N, 1, sM)); continue; }
+      Nd4WsScope scope3(h);
+      void* q = nullptr;
+      ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)N * N + 2 * (size_t)N * r), &q));
+      double* Qf = static_cast<double*>(q);
+      double* VrT = Qf + (size_t)N * N;
+      double* Rf = VrT + (size_t)N * r;
+      ND4_TRY(nd4_transpose(h, r, N, Vm, N, VrT, r, 1, 0, 0));
+      ND4_TRY(nd4_geqrf_q_ex(h, 1, N, r, VrT, Qf, Rf, true));
+      ND4_TRY(nd4_transpose(h, N, N - r, Qf + r, N, Vm + (size_t)r * N, N, 1, 0, 0));
+    }
+  }
   ND4_TRY(nd4_transpose(h, N, N, Utp, N, U, N, batch, sM, sM));
   if (sweeps_out) *sweeps_out = sweeps;
   if (offnorm_out) { double r; unsigned long long b = last_off; memcpy(&r, &b, 8); *offnorm_out = sqrt(r); }

@@ -154,3 +154,12 @@ def test_padded_block_path_structured(la):
         check_properties(a, u, sv, v)
         ref = np.linalg.svd(a, compute_uv=False)
         assert np.abs(sv - ref).max() <= 1e-12 * max(ref.max(), 1e-300)
+
+
+@pytest.mark.parametrize("N,r", [(512, 1), (512, 64), (1000, 3), (256, 255)])
+def test_rank_deficient_completion_by_qr(la, N, r):
+    """N >= 128: the null-space rows of V come from one full QR of the valid right vectors (not built one by one)"""
+    a = rng.matrix(1500 + N, N, r) @ rng.matrix(1501 + r, r, N)
+    u, sv, v = la.svd_decomp(a)
+    check_properties(a, u, sv, v, slack=4.0)
+    assert np.all(sv[r:] <= 1e-10 * sv[0]) and sv[r - 1] > 1e-6 * sv[0]
