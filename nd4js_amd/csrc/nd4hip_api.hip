@@ -52,6 +52,11 @@ int d2h(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
 }
 constexpr size_t D = sizeof(double);
 
+// The kernels carry the batch in gridDim.y/z (<= 65535): longer batches run in chunks of ND4_CHUNK matrices. `b0` is the
+// first matrix of the chunk, `nb` its length; strides that are 0 (broadcast operand) stay 0.
+constexpr int64_t ND4_CHUNK = 32768;
+#define ND4_FOR_CHUNKS(batch) for (int64_t b0 = 0, nb = 0; (nb = ((batch) - b0 < ND4_CHUNK ? (batch) - b0 : ND4_CHUNK)) > 0; b0 += nb)
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ matmul
@@ -105,7 +110,8 @@ extern "C" int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && LU && P, "nd4hip_dgetrf_batched: NULL pointer");
-  return nd4_getrf(h, batch, N, A, LU, P);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_getrf(h, nb, N, A + b0 * N * N, LU + b0 * N * N, P + b0 * N));
+  return 0;
 }
 extern "C" int nd4hip_dgetrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
@@ -138,7 +144,8 @@ extern "C" int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                 "nd4hip_dgetrs_batched: a stride must be 0 or at least the size of one operand");
   if (batch == 0 || N == 0 || J == 0) return 0;
   ND4_CHECK_ARG(LU && P && Y && X, "nd4hip_dgetrs_batched: NULL pointer");
-  return nd4_getrs(h, batch, N, J, LU, strideLU, P, strideP, Y, strideY, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_getrs(h, nb, N, J, LU + b0 * strideLU, strideLU, P + b0 * strideP, strideP, Y + b0 * strideY, strideY, X + b0 * N * J));
+  return 0;
 }
 extern "C" int nd4hip_dgetrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
                                      const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
@@ -169,7 +176,8 @@ extern "C" int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_di
   if (batch == 0 || M == 0 || J == 0) return 0;
   ND4_CHECK_ARG(T && Y && X, "nd4hip_dtrsm_batched: NULL pointer");
   if (X != Y || strideY != M * J) ND4_TRY(copy_rhs(h, batch, M, J, Y, strideY, X));
-  return nd4_trsm(h, upper != 0, unit_diag != 0, batch, M, J, T, strideT, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_trsm(h, upper != 0, unit_diag != 0, nb, M, J, T + b0 * strideT, strideT, X + b0 * M * J));
+  return 0;
 }
 extern "C" int nd4hip_dtrsm_batched(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
                                     const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
@@ -202,7 +210,8 @@ extern "C" int nd4hip_dqrls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t
   ND4_CHECK_ARG(X != nullptr, "nd4hip_dqrls_batched: NULL pointer");
   if (N == 0 || M == 0) { ND4_HIP(hipMemsetAsync(X, 0, D * (size_t)(batch * I * J), h->stream)); return 0; }
   ND4_CHECK_ARG(Q && R && Y, "nd4hip_dqrls_batched: NULL pointer");
-  return nd4_qrls(h, batch, N, M, I, J, Q, strideQ, R, strideR, Y, strideY, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_qrls(h, nb, N, M, I, J, Q + b0 * strideQ, strideQ, R + b0 * strideR, strideR, Y + b0 * strideY, strideY, X + b0 * I * J));
+  return 0;
 }
 extern "C" int nd4hip_dqrls_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
                                     const double* Q, int64_t strideQ, const double* R, int64_t strideR,
@@ -238,7 +247,9 @@ extern "C" int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   ND4_CHECK_ARG(X != nullptr, "nd4hip_dsvdls_batched: NULL pointer");
   if (N == 0 || M == 0) { ND4_HIP(hipMemsetAsync(X, 0, D * (size_t)(batch * I * J), h->stream)); return 0; }
   ND4_CHECK_ARG(U && sv && V && Y, "nd4hip_dsvdls_batched: NULL pointer");
-  return nd4_svdls(h, batch, N, M, I, J, U, strideU, sv, strideSv, V, strideV, Y, strideY, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_svdls(h, nb, N, M, I, J, U + b0 * strideU, strideU, sv + b0 * strideSv, strideSv, V + b0 * strideV, strideV,
+                                          Y + b0 * strideY, strideY, X + b0 * I * J));
+  return 0;
 }
 extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J,
                                      const double* U, int64_t strideU, const double* sv, int64_t strideSv,
@@ -279,7 +290,7 @@ extern "C" int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   void* p = nullptr;
   ND4_TRY(nd4_ws_alloc(h, sizeof(int) * (size_t)batch, &p));
   int* flags = static_cast<int*>(p);
-  ND4_TRY(nd4_potrf(h, batch, N, S, L, flags));
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_potrf(h, nb, N, S + b0 * N * N, L + b0 * N * N, flags + b0));
   // the reference throws on the first NaN pivot (cholesky.js:43-44): one small read-back decides it
   void* hp = nullptr;
   ND4_TRY(nd4_pinned(h, sizeof(int) * (size_t)batch, &hp));
@@ -312,7 +323,8 @@ extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                 "nd4hip_dpotrs_batched: a stride must be 0 or at least the size of one operand");
   if (batch == 0 || N == 0 || J == 0) return 0;
   ND4_CHECK_ARG(L && Y && X, "nd4hip_dpotrs_batched: NULL pointer");
-  return nd4_potrs(h, batch, N, J, L, strideL, Y, strideY, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_potrs(h, nb, N, J, L + b0 * strideL, strideL, Y + b0 * strideY, strideY, X + b0 * N * J));
+  return 0;
 }
 extern "C" int nd4hip_dpotrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
                                      const double* Y, int64_t strideY, double* X) {
@@ -338,7 +350,8 @@ extern "C" int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(S && LD, "nd4hip_dldltrf_batched: NULL pointer");
-  return nd4_ldltrf(h, batch, N, S, LD);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_ldltrf(h, nb, N, S + b0 * N * N, LD + b0 * N * N));
+  return 0;
 }
 extern "C" int nd4hip_dldltrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
@@ -362,7 +375,8 @@ extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64
                 "nd4hip_dldltrs_batched: a stride must be 0 or at least the size of one operand");
   if (batch == 0 || N == 0 || J == 0) return 0;
   ND4_CHECK_ARG(LD && Y && X, "nd4hip_dldltrs_batched: NULL pointer");
-  return nd4_ldltrs(h, batch, N, J, LD, strideLD, Y, strideY, X);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_ldltrs(h, nb, N, J, LD + b0 * strideLD, strideLD, Y + b0 * strideY, strideY, X + b0 * N * J));
+  return 0;
 }
 extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
                                       const double* Y, int64_t strideY, double* X) {
@@ -388,7 +402,9 @@ extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && B && V, "nd4hip_dgebrd_batched: NULL pointer");
-  return nd4_gebrd(h, batch, M, N, A, U, B, V);
+  { const int64_t K = M < N ? M : N, Jb = M >= N ? K : K + 1;
+    ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_gebrd(h, nb, M, N, A + b0 * M * N, U + b0 * M * K, B + b0 * K * Jb, V + b0 * Jb * N)); }
+  return 0;
 }
 extern "C" int nd4hip_dgebrd_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
@@ -412,7 +428,8 @@ extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && H, "nd4hip_dgehrd_batched: NULL pointer");
-  return nd4_gehrd(h, batch, N, A, U, H);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_gehrd(h, nb, N, A + b0 * N * N, U + b0 * N * N, H + b0 * N * N));
+  return 0;
 }
 extern "C" int nd4hip_dgehrd_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
@@ -435,7 +452,9 @@ extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int6
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_q_batched: NULL pointer");
-  return nd4_geqrf_q(h, batch, M, N, A, Q, R);
+  { const int64_t L = M < N ? M : N;
+    ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_geqrf_q(h, nb, M, N, A + b0 * M * N, Q + b0 * M * L, R + b0 * L * N)); }
+  return 0;
 }
 extern "C" int nd4hip_dgeqrf_q_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
@@ -459,7 +478,8 @@ extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, i
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_full_batched: NULL pointer");
-  return nd4_geqrf_q_ex(h, batch, M, N, A, Q, R, true);
+  ND4_FOR_CHUNKS(batch) ND4_TRY(nd4_geqrf_q_ex(h, nb, M, N, A + b0 * M * N, Q + b0 * M * M, R + b0 * M * N, true));
+  return 0;
 }
 extern "C" int nd4hip_dgeqrf_full_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
@@ -522,7 +542,19 @@ extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64
   if (offnorm_out) *offnorm_out = 0.0;
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && sv && V, "nd4hip_dgesvdj_batched: NULL pointer");
-  return nd4_gesvdj(h, batch, M, N, A, U, sv, V, sweeps_out, offnorm_out);
+  {
+    const int64_t L = M < N ? M : N;
+    int sweeps = 0; double off = 0.0;
+    ND4_FOR_CHUNKS(batch) {
+      int sw = 0; double of = 0.0;
+      ND4_TRY(nd4_gesvdj(h, nb, M, N, A + b0 * M * N, U + b0 * M * L, sv + b0 * L, V + b0 * L * N, &sw, &of));
+      if (sw > sweeps) sweeps = sw;
+      if (of > off) off = of;
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    if (offnorm_out) *offnorm_out = off;
+  }
+  return 0;
 }
 extern "C" int nd4hip_dgesvdj_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                       double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {

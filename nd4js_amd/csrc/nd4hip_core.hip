@@ -193,8 +193,11 @@ __global__ void copy_matrix_kernel(int64_t rows, int64_t cols, const double* __r
 int nd4_copy_matrix(nd4hip_handle* h, int64_t rows, int64_t cols, const double* src, int64_t lds,
                     double* dst, int64_t ldd, int64_t batch, int64_t ssrc, int64_t sdst) {
   if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
-  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 1024 ? rows : 1024), (unsigned)batch);
-  hipLaunchKernelGGL(copy_matrix_kernel, grid, dim3(256), 0, h->stream, rows, cols, src, lds, dst, ldd, ssrc, sdst);
+  for (int64_t b0 = 0; b0 < batch; b0 += 32768) {                  // gridDim.z limit
+    const int64_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 1024 ? rows : 1024), (unsigned)nb);
+    hipLaunchKernelGGL(copy_matrix_kernel, grid, dim3(256), 0, h->stream, rows, cols, src + b0 * ssrc, lds, dst + b0 * sdst, ldd, ssrc, sdst);
+  }
   ND4_HIP(hipGetLastError());
   return 0;
 }

@@ -80,3 +80,25 @@ def test_large_batch_of_small_matrices(la):
     u, sv, v = la.svd_decomp(a[:64])
     _, rsv, _, _ = oracle.svd_jac_2sided(a[:64])
     assert np.abs(sv - rsv).max() <= 1e-12 * rsv.max()
+
+
+def test_batches_longer_than_the_grid_limit():
+    """more than 65535 matrices in one call: every entry point runs them in chunks"""
+    from nd4js_amd import la
+    b = 70000
+    a = rng.matrix(7100, b, 4, 4)
+    y = rng.matrix(7101, b, 4, 2)
+    lu, p = la.lu_decomp(a)
+    x = la.lu_solve(lu, p, y)
+    assert np.abs(a @ x - y).max() <= 1e-8
+    q, r = la.qr_decomp(a)
+    assert np.abs(q @ r - a).max() <= 1e-13
+    s = a @ np.swapaxes(a, -1, -2) + 4 * np.eye(4)
+    L = la.cholesky_decomp(s)
+    assert np.abs(L @ np.swapaxes(L, -1, -2) - s).max() <= 1e-12
+    u, sv, v = la.svd_decomp(a)
+    assert np.abs((u * sv[..., None, :]) @ v - a).max() <= 1e-12
+    assert np.abs(la.matmul2(a, y) - a @ y).max() <= 1e-13
+    last = slice(b - 3, b)
+    uo, so, vo = la.svd_decomp(a[last])
+    assert np.allclose(sv[last], so, rtol=0, atol=1e-13)           # the tail chunk is really computed, not left behind
