@@ -369,13 +369,14 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
 }
 
 // ---- the same panel kernel for 2048 < m <= 4096 rows: 1024 threads leave 128 VGPRs per lane = R = 4 rows of EIGHT columns.
-// A 16-column panel slot is then factorised in two halves (half = 0 / 1, columns c0 = j0 + 8 half): half 0 writes T[0:8,0:8]
-// and zeroes the rest of the slot, so that the ordinary block-reflector machinery can apply (v_0..v_7) to columns 8..15
-// while V[:, 8:16] is still zero; half 1 writes T[8:16,8:16]; qr_t12_finish completes T[0:8,8:16] = -T11 (V1^T V2) T22.
+// A 16-column panel slot is then factorised in parts (two 8-column halves here, four 4-column quarters in qr_panel_row4).
+// Every part writes ONLY its own triangular factor into the live T slot (zeros elsewhere), so that the ordinary
+// block-reflector machinery applies just this part's reflectors to the remaining columns of the slot, and also into a
+// side slot that collects the diagonal blocks; qr_t_assemble then builds the full 16 x 16 factor from them and V^T V.
 template <int R>
 __global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, int M, long ld, long strideW,
                                                      double* __restrict__ Vall, long ldv, long strideV,
-                                                     double* __restrict__ Tall, long strideT,
+                                                     double* __restrict__ Tall, double* __restrict__ Tside, long strideT,
                                                      double* __restrict__ taus, long strideTau, int c0, int nb) {
   constexpr int W8 = 8, NW = 16;                       // columns of this kernel, waves per workgroup
   __shared__ double s_red[NW];
@@ -528,12 +529,179 @@ __global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, i
     }
   }
   if (t < 16 * 16) {                                     // the 16 x 16 slot of the enclosing panel
-    const int slot0 = (c0 / 16) * 16, half = (c0 - slot0) / 8;
+    const int slot0 = (c0 / 16) * 16, part = (c0 - slot0) / W8;
     const int i = t / 16, j = t % 16;
-    double* Ts = Tall + blockIdx.x * strideT + (long)(slot0 / 16) * 256;
-    const bool mine = (i / 8 == half) && (j / 8 == half);
-    if (mine) Ts[t] = ((i & 7) <= (j & 7) && (j & 7) < nb) ? s_T[i & 7][j & 7] : 0.0;
-    else if (half == 0) Ts[t] = 0.0;
+    const long so = blockIdx.x * strideT + (long)(slot0 / 16) * 256;
+    const bool mine = (i / W8 == part) && (j / W8 == part);
+    const double val = (mine && (i % W8) <= (j % W8) && (j % W8) < nb) ? s_T[i % W8][j % W8] : 0.0;
+    Tall[so + t] = val;                                  // live slot: ONLY this part's block (the partial block reflector)
+    if (mine) Tside[so + t] = val;                       // side slot: collects the diagonal blocks of all parts
+  }
+}
+
+// four 4-column quarters: R = 8 rows x 4 columns per lane, 4096 < m <= 8192 rows
+template <int R>
+__global__ __launch_bounds__(1024) void qr_panel_row4(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                     double* __restrict__ Vall, long ldv, long strideV,
+                                                     double* __restrict__ Tall, double* __restrict__ Tside, long strideT,
+                                                     double* __restrict__ taus, long strideTau, int c0, int nb) {
+  constexpr int W8 = 4, NW = 16;                       // columns of this kernel, waves per workgroup
+  __shared__ double s_red[NW];
+  __shared__ double s_w[NW][W8];
+  __shared__ double s_T[W8][W8 + 1];
+  __shared__ double s_Z[W8][W8];
+  __shared__ double s_tau[W8];
+  const int j0 = c0;                                   // rows and columns of this half start at its own diagonal
+  __shared__ double s_alpha;
+  double* A = Wm + blockIdx.x * strideW;
+  double* V = Vall + blockIdx.x * strideV;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const int mycol = (b0 ? 2 : 0) + (b1 ? 1 : 0);                                  // column this lane ends up with
+
+  double a[R][W8];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + 1024 * i;
+#pragma unroll
+    for (int c = 0; c < W8; c++) a[i][c] = 0.0;
+    if (r < M) {
+      const double* src = A + (long)r * ld + j0;
+      if (nb == W8 && (ld & 1) == 0) {                   // 16-byte loads of the lane's own 128-B row segment
+#pragma unroll
+        for (int c = 0; c < W8; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < nb) a[i][c] = src[c];
+      }
+    }
+  }
+  if (t < W8 * (W8 + 1)) (&s_T[0][0])[t] = 0.0;
+
+  // one column step per compile-time k (generic lambda, see lu.hip: convergent DPP ops block `#pragma unroll`)
+  auto column_step = [&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if (k < nb) {
+      const int jc = j0 + k;
+      double part = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        if (r > jc) part += a[i][k] * a[i][k];
+      }
+      if (t == k) s_alpha = a[0][k];
+      part = nd4dpp::wave_sum(part);
+      if (lane == 0) s_red[wave] = part;
+      __syncthreads();
+      double sigma = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) sigma += s_red[w];
+      const double alpha = s_alpha;
+      double beta = alpha, tau = 0.0, scale = 0.0;
+      if (sigma != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      double vr[R], d[W8];
+#pragma unroll
+      for (int c = 0; c < W8; c++) d[c] = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+#pragma unroll
+        for (int c = 0; c < W8; c++) d[c] += vr[i] * a[i][c];
+      }
+      // halving butterfly over the 4 lanes of a group (2 + 1 exchanges), then across the 16 groups of the wave
+      double e2[2], e1;
+#pragma unroll
+      for (int j = 0; j < 2; j++) { const double snd = b0 ? d[j] : d[j + 2], kp = b0 ? d[j + 2] : d[j]; e2[j] = kp + nd4dpp::xor1(snd); }
+      { const double snd = b1 ? e2[0] : e2[1], kp = b1 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor2(snd); }
+      e1 += nd4dpp::xor4(e1);
+      e1 += nd4dpp::xor8(e1);
+      e1 += __shfl_xor(e1, 16);
+      e1 += __shfl_xor(e1, 32);
+      if (lane < W8) s_w[wave][mycol] = e1;
+      __syncthreads();
+      double tot = 0.0;                                   // lane -> column lane & 3
+#pragma unroll
+      for (int w = 0; w < NW; w++) tot += s_w[w][lane & 3];
+      double wv[W8];                                      // wave-uniform totals
+#define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
+      ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3)
+#undef ND4_RL
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = j0 + t + 1024 * i;
+        const double tv = tau * vr[i];
+#pragma unroll
+        for (int c = k + 1; c < W8; c++) a[i][c] -= tv * wv[c];
+        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < k) s_Z[k][c] = wv[c];
+        s_tau[k] = tau;
+        taus[blockIdx.x * strideTau + j0 + k] = tau;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define ND4_STEP(K) column_step(std::integral_constant<int, K>{});
+  ND4_STEP(0) ND4_STEP(1) ND4_STEP(2) ND4_STEP(3)
+#undef ND4_STEP
+  __syncthreads();
+  if (t < nb) {                                          // larft: row t of T depends only on row t
+    double row[W8];
+#pragma unroll
+    for (int k = 0; k < W8; k++) row[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < W8; k++) {
+      if (k == t) row[k] = s_tau[k];
+      else if (k > t && k < nb) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < W8; j++) if (j >= t && j < k) sum += row[j] * s_Z[k][j];
+        row[k] = -s_tau[k] * sum;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W8; k++) s_T[t][k] = row[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int lr = t + 1024 * i, r = j0 + lr;
+    if (r < M) {
+      double* w = A + (long)r * ld + j0;
+      double* v = V + (long)r * ldv + j0;
+      double wv[W8], vv[W8];
+#pragma unroll
+      for (int c = 0; c < W8; c++) {
+        wv[c] = (lr <= c) ? a[i][c] : 0.0;                       // R part (upper triangle incl. diagonal)
+        vv[c] = (lr < c) ? 0.0 : ((lr == c) ? 1.0 : a[i][c]);    // explicit reflector: zeros above, unit diagonal
+      }
+      if (nb == W8 && (ld & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < W8; c += 2) {
+          *reinterpret_cast<double2*>(w + c) = double2{wv[c], wv[c + 1]};
+          *reinterpret_cast<double2*>(v + c) = double2{vv[c], vv[c + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W8; c++) if (c < nb) { w[c] = wv[c]; v[c] = vv[c]; }
+      }
+    }
+  }
+  if (t < 16 * 16) {                                     // the 16 x 16 slot of the enclosing panel
+    const int slot0 = (c0 / 16) * 16, part = (c0 - slot0) / W8;
+    const int i = t / 16, j = t % 16;
+    const long so = blockIdx.x * strideT + (long)(slot0 / 16) * 256;
+    const bool mine = (i / W8 == part) && (j / W8 == part);
+    const double val = (mine && (i % W8) <= (j % W8) && (j % W8) < nb) ? s_T[i % W8][j % W8] : 0.0;
+    Tall[so + t] = val;                                  // live slot: ONLY this part's block (the partial block reflector)
+    if (mine) Tside[so + t] = val;                       // side slot: collects the diagonal blocks of all parts
   }
 }
 
@@ -659,24 +827,32 @@ __global__ void qr_flip_cols(double* __restrict__ X, long ld, long strideX, int 
   for (int r = blockIdx.y; r < rows; r += gridDim.y) X[(long)r * ld + col] = -X[(long)r * ld + col];
 }
 
-// T[0:8, 8:16] = -T11 (V1^T V2) T22 for a 16-column slot factorised in two halves; G = V1^T V2 (8 x 8, row-major)
-__global__ __launch_bounds__(64) void qr_t12_finish(double* __restrict__ Tall, long strideT, int panel, const double* __restrict__ Gm, long sG) {
-  __shared__ double s_t[16][17], s_g[8][9], s_x[8][9];
-  double* T = Tall + blockIdx.x * strideT + (long)panel * 256;
-  const double* G = Gm + blockIdx.x * sG;
-  const int t = threadIdx.x, i = t / 8, j = t % 8;
-  for (int e = t; e < 256; e += 64) s_t[e / 16][e % 16] = T[e];
-  s_g[i][j] = G[t];
+// Full 16 x 16 triangular factor of a slot that was factorised in parts of bs columns: the diagonal blocks come from the
+// side slot, the rest from T[1,2] = -T1 (V1^T V2) T2 applied level by level (groups of bs, 2 bs, ... columns); G = V^T V of
+// the slot's 16 reflector columns (row-major 16 x 16). One small workgroup per matrix.
+__global__ __launch_bounds__(256) void qr_t_assemble(double* __restrict__ Tall, const double* __restrict__ Tside, long strideT, int panel,
+                                                      const double* __restrict__ Gm, long sG, int bs) {
+  __shared__ double s_t[16][17], s_g[16][17], s_x[16][17];
+  const long so = blockIdx.x * strideT + (long)panel * 256;
+  const int t = threadIdx.x, i = t / 16, j = t % 16;
+  s_t[i][j] = Tside[so + t];
+  s_g[i][j] = Gm[blockIdx.x * sG + t];
   __syncthreads();
-  double x = 0.0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) x += s_g[i][q] * s_t[8 + q][8 + j];       // G T22
-  s_x[i][j] = x;
-  __syncthreads();
-  double y = 0.0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) y += s_t[i][q] * s_x[q][j];               // T11 (G T22)
-  T[i * 16 + 8 + j] = -y;
+  for (int b = bs; b < 16; b *= 2) {
+    // thread (i, j) with i in the first group of its pair and j in the second: x = (G12 T2)[i][j], then T12 = -T1 x
+    const int pair0 = (i / (2 * b)) * 2 * b;
+    const bool on = (i - pair0) < b && j >= pair0 + b && j < pair0 + 2 * b;
+    double x = 0.0;
+    if (on) for (int q = pair0 + b; q < pair0 + 2 * b; q++) x += s_g[i][q] * s_t[q][j];
+    s_x[i][j] = x;
+    __syncthreads();
+    double y = 0.0;
+    if (on) for (int q = pair0; q < pair0 + b; q++) y += s_t[i][q] * s_x[q][j];
+    __syncthreads();
+    if (on) s_t[i][j] = -y;
+    __syncthreads();
+  }
+  Tall[so + t] = s_t[i][j];
 }
 
 template <int R>
@@ -717,7 +893,7 @@ void launch_panel(nd4hip_handle* h, int batch, double* W, int M, long ld, long s
 }
 
 struct QrWs {
-  double *V, *T, *taus, *Wp, *W2, *work; int* flips;
+  double *V, *T, *Tside, *taus, *Wp, *W2, *work; int* flips;
   long ldv, sV, sT, sTau, ldw, sChunk, sWb, sW2;
   int nchunks_max;
 };
@@ -822,7 +998,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   ws.sWb = ws.sChunk * ws.nchunks_max;
   ws.sW2 = ws.sChunk;
   const long sWork = tall ? (long)M * N : 0;
-  size_t doubles = (size_t)batch * (ws.sV + ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
+  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
   size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + 64;
   void* p = nullptr;
   Nd4WsScope scope(h);
@@ -830,6 +1006,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   double* d = static_cast<double*>(p);
   ws.V = d; d += (size_t)batch * ws.sV;
   ws.T = d; d += (size_t)batch * ws.sT;
+  ws.Tside = d; d += (size_t)batch * ws.sT;                 // diagonal blocks of slots factorised in parts (tall panels)
   ws.taus = d; d += (size_t)batch * ws.sTau;
   ws.Wp = d; d += (size_t)batch * ws.sWb;
   ws.W2 = d; d += (size_t)batch * ws.sW2;
@@ -847,26 +1024,32 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   }
   hipLaunchKernelGGL(qr_scale_apply, dim3((unsigned)((sW + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, A, W, sW, exps, -1);
   ND4_HIP(hipMemsetAsync(ws.V, 0, sizeof(double) * (size_t)batch * ws.sV, h->stream));
+  if (M > 2048) ND4_HIP(hipMemsetAsync(ws.Tside, 0, sizeof(double) * (size_t)batch * ws.sT, h->stream));
 
   // ---- factorisation: panels left to right ----
   for (int pnl = 0; pnl < npanels; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
     const int Rn = (m + 63) / 64;
     static const bool tall8_off = [] { const char* e = getenv("ND4HIP_QR_NO_TALL8"); return e && *e && *e != '0'; }();
-    if (!tall8_off && m > 2048 && m <= 4096) {
-      // two 8-column halves on 1024 threads (qr_panel_row8): half 0, its reflectors applied to the other 8 columns, half 1,
-      // then T12 = -T11 (V1^T V2) T22 from one small split-K Gram product
-      const int nb1 = nb < 8 ? nb : 8;
-      hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb1);
-      ND4_HIP(hipGetLastError());
-      if (nb > 8) {
-        ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + 8, ld, sW, nb - 8));
-        hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau,
-                           j0 + 8, nb - 8);
+    if (!tall8_off && m > 2048 && m <= 8192) {
+      // the 16-column slot in parts on 1024 threads: two 8-column halves (m <= 4096: 4 rows x 8 columns per lane) or four
+      // 4-column quarters (m <= 8192: 8 rows x 4 columns per lane). After each part its reflectors are applied to the rest
+      // of the slot (the live T holds only that part's block); at the end T is assembled from the side blocks and V^T V.
+      const int w = m <= 4096 ? 8 : 4;
+      for (int c = 0; c < nb; c += w) {
+        const int nbp = nb - c < w ? nb - c : w;
+        if (w == 8) hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
+                                       ws.taus, ws.sTau, j0 + c, nbp);
+        else        hipLaunchKernelGGL((qr_panel_row4<8>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
+                                       ws.taus, ws.sTau, j0 + c, nbp);
         ND4_HIP(hipGetLastError());
-        const double* V1 = ws.V + (long)j0 * ws.ldv + j0;
-        ND4_TRY(nd4_gemm(h, true, false, 8, 8, m, 1.0, V1, ws.ldv, ws.sV, V1 + 8, ws.ldv, ws.sV, 0.0, ws.W2, 8, ws.sW2, batch));
-        hipLaunchKernelGGL(qr_t12_finish, dim3(batch), dim3(64), 0, h->stream, ws.T, ws.sT, pnl, ws.W2, ws.sW2);
+        if (c + w < nb)
+          ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + c + w, ld, sW, nb - c - w));
+      }
+      if (nb > w) {
+        const double* Vs = ws.V + (long)j0 * ws.ldv + j0;
+        ND4_TRY(nd4_gemm(h, true, false, NB, NB, m, 1.0, Vs, ws.ldv, ws.sV, Vs, ws.ldv, ws.sV, 0.0, ws.W2, NB, ws.sW2, batch));
+        hipLaunchKernelGGL(qr_t_assemble, dim3(batch), dim3(256), 0, h->stream, ws.T, ws.Tside, ws.sT, pnl, ws.W2, ws.sW2, w);
         ND4_HIP(hipGetLastError());
       }
     } else

@@ -230,9 +230,11 @@ def test_tsqr_lstsq_and_svd_chain(la):
     assert np.linalg.norm((u * sv) @ v - b) <= 1e-12 * np.linalg.norm(b) and np.abs(u.T @ u - np.eye(12)).max() <= 1e-13
 
 
-@pytest.mark.parametrize("shape", [(2100, 2100), (2049, 2056), (3000, 3000), (4096, 4096), (2, 2200, 2200), (3000, 2500)])
+@pytest.mark.parametrize("shape", [(2100, 2100), (2049, 2056), (3000, 3000), (4096, 4096), (2, 2200, 2200), (3000, 2500),
+                                   (4200, 4200), (4100, 4107)])
 def test_two_half_panels_beyond_2048_rows(la, shape):
-    """2048 < m <= 4096 rows: every 16-column panel is factorised as two 8-column halves on 1024 threads."""
+    """2048 < m <= 4096 rows: every 16-column panel is factorised as two 8-column halves on 1024 threads;
+    4096 < m <= 8192: as four 4-column quarters."""
     a = rng.matrix(4700 + shape[-2], *shape)
     q, r = la.qr_decomp(a)
     check_properties(a, q, r)
