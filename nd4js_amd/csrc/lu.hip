@@ -410,38 +410,45 @@ __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, in
   }
 }
 
-// ---- apply the panel's row swaps to the columns outside the panel ------------------------------
-__global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, long strideM, int j0, int nb, const int32_t* __restrict__ ipiv) {
+// ---- apply the panel's row swaps to the columns outside the panel, and (fused) U12 = L11^-1 A12 for the columns to
+// its right: both are one-thread-per-column jobs over the same columns, and the 16 swapped-in pivot rows are exactly the
+// rows the triangular solve works on, so they never leave the registers in between. One launch per panel instead of two.
+__global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, long strideM, int j0, int nb, const int32_t* __restrict__ ipiv,
+                                                int do_swap) {
+  __shared__ double s_l[NB][NB + 1];
+  __shared__ int s_piv[NB];
   double* A = LU + blockIdx.y * strideM;
   const int32_t* ip = ipiv + (long)blockIdx.y * N;
-  int col = blockIdx.x * blockDim.x + threadIdx.x;       // index among the N - nb outside columns
-  if (col >= N - nb) return;
-  if (col >= j0) col += nb;
-  for (int k = 0; k < nb; k++) {
-    const int r = j0 + k, pv = ip[r];
-    if (pv != r) {
-      const double x = A[(long)r * N + col];
-      A[(long)r * N + col] = A[(long)pv * N + col];
-      A[(long)pv * N + col] = x;
-    }
-  }
-}
-
-// ---- U12 = L11^-1 * A12, L11 unit lower nb x nb at (j0,j0); A12 = rows j0.. , cols [c0, N) -------
-__global__ __launch_bounds__(256) void lu_trsm(double* __restrict__ LU, int N, long strideM, int j0, int nb) {
-  __shared__ double s_l[NB][NB + 1];
-  double* A = LU + blockIdx.y * strideM;
   const int t = threadIdx.x;
-  if (t < NB * NB) {
-    const int i = t / NB, j = t % NB;
+  {
+    const int i = t / NB, j = t % NB;                        // 256 threads = NB * NB
     s_l[i][j] = (i < nb && j < i) ? A[(long)(j0 + i) * N + j0 + j] : 0.0;
+    if (t < NB) s_piv[t] = (t < nb) ? ip[j0 + t] : j0 + t;
   }
   __syncthreads();
-  const int col = j0 + nb + blockIdx.x * blockDim.x + t;
-  if (col >= N) return;
+  int col = blockIdx.x * blockDim.x + t;                   // index among the N - nb outside columns
+  if (col >= N - nb) return;
+  const bool right = col >= j0;
+  if (right) col += nb;
   double x[NB];
 #pragma unroll
-  for (int i = 0; i < NB; i++) x[i] = (i < nb) ? A[(long)(j0 + i) * N + col] : 0.0;
+  for (int k = 0; k < NB; k++) {                           // swap k: rows j0 + k <-> piv_k; x[k] ends up with row j0 + k
+    x[k] = 0.0;
+    if (k < nb) {
+      const int r = j0 + k, pv = s_piv[k];
+      double top = A[(long)r * N + col];
+      if (do_swap && pv != r) {
+        // the pivot row may itself be one of the panel's later top rows (pv < j0 + nb): then it is still in memory,
+        // not yet in x[], because x[] only holds rows that were already finalised (k' < k)
+        const double other = A[(long)pv * N + col];
+        A[(long)pv * N + col] = top;
+        top = other;
+      }
+      x[k] = top;
+      if (!right && do_swap && pv != r) A[(long)r * N + col] = top;
+    }
+  }
+  if (!right) return;
 #pragma unroll
   for (int i = 1; i < NB; i++) {
     double s = x[i];
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void lu_trsm(double* __restrict__ LU, int N, l
     x[i] = s;
   }
 #pragma unroll
-  for (int i = 1; i < NB; i++)
+  for (int i = 0; i < NB; i++)
     if (i < nb) A[(long)(j0 + i) * N + col] = x[i];
 }
 
@@ -538,13 +545,11 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
       int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
       hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
     }
-    if (N > nb && !nopivot)
-      hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                         LU, N, strideM, j0, nb, ipiv);
     const int rest = N - j0 - nb;
+    if (N > nb && (!nopivot || rest > 0))
+      hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                         LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1);
     if (rest > 0) {
-      hipLaunchKernelGGL(lu_trsm, dim3((unsigned)((rest + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                         LU, N, strideM, j0, nb);
       ND4_HIP(hipGetLastError());
       double* base = LU;
       ND4_TRY(nd4_gemm(h, false, false, rest, rest, nb, -1.0,
