@@ -2,15 +2,17 @@
 //
 // Replaces src/la/lu.js:24-81 (unblocked Doolittle, first-maximum row pivoting, full-row swaps,
 // permutation VECTOR output). Per block column of width NB = 16:
-//   lu_panel   one workgroup per matrix factors rows [j0,N) x cols [j0,j0+nb): per column a
+//   lu_panel_* one workgroup per matrix factors rows [j0,N) x cols [j0,j0+nb): per column a
 //              wave-shuffle + LDS arg-max (ties -> lowest row, exactly the reference's strict '>' scan,
-//              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. 16 lanes own one row
-//              (one lane per panel column) so every row access is one coalesced 128-byte line.
-//              The fast variant keeps the whole panel in registers (<= 48 rows x 1 column per lane).
-//   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61
-//              swaps full rows), one thread per column -> coalesced.
-//   lu_trsm    U12 = L11^-1 * A12 (unit lower 16x16 in LDS, one thread per column).
-//   nd4_gemm   A22 -= L21 * U12 on the fp64 MFMA GEMM (gemm.hip).
+//              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. lu_panel_row<R>: one thread per
+//              row, the R x 16 tile of each lane in registers (m <= 2048); lu_panel_row_wt<R,W,T>: the same on
+//              1024 threads with 8- / 4-column panels (m <= 4096 / 8192); lu_panel_reg / lu_panel_global: 16 lanes
+//              per row / panel in global memory (anything taller).
+//   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61 swaps full
+//              rows) and, in the same pass, U12 = L11^-1 * A12 for the columns to the right (unit lower
+//              16x16 in LDS), one thread per column -> coalesced.
+//   nd4_gemm   A22 -= L21 * U12 on the fp64 MFMA GEMM (gemm.hip, rank-k kernel).
+//   lu_build_perm  P from the recorded interchanges, once per factorisation.
 #include "nd4hip_internal.h"
 #include "dpp.h"
 #include <type_traits>
