@@ -254,6 +254,126 @@ __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpa
   }
 }
 
+// The same rotation rounds on 8 or 16 waves (512 / 1024 threads): each wave carries 4 or 2 of the 32 disjoint pairs of a
+// round instead of 8 (2048^2: 115.7 ms with 4 waves, 98.1 with 8, 95.0 with 16).
+// The rounds are LDS-latency bound (read 2 rows / 2 columns, rotate, write back, barrier), and with only nblk/2 workgroups
+// in flight for a single large matrix the chip is mostly idle: twice the waves per workgroup hide that latency better.
+template <int PW>                                      // pairs per wave: 4 -> 8 waves, 2 -> 16 waves
+__global__ __launch_bounds__(2048 / PW) void jacb_eigen8(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                                   JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                                   double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                                   unsigned long long* __restrict__ offmax, int max_inner, int cross_only) {
+  __shared__ double G[PB][PB + 1];
+  __shared__ double Q[PB][PB + 1];
+  __shared__ unsigned s_rot[32 / PW];
+  const int pairIdx = blockIdx.x, mat = blockIdx.y;
+  if (st[mat].done) return;
+  int I, J;
+  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  if (J >= nblk) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  {
+    const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
+    for (int e = t; e < PB * PB; e += 2048 / PW) {
+      double s = 0.0;
+      for (int ch = 0; ch < nchunks; ch++) s += Gp[(long)ch * (PB * PB) + e];
+      G[e / PB][e % PB] = s;
+      Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  const double fl = floor2[mat];
+  unsigned total = 0;
+  double relmax = 0.0;
+  // converged pairs (the common case in the last sweeps) leave after one pass over the off-diagonal
+  {
+    int need = 0;
+    for (int e = t; e < PB * PB; e += 2048 / PW) {
+      const int i = e / PB, j = e % PB;
+      if (i < j) { const double a = G[i][i], b = G[j][j], g = G[i][j]; need |= (a > fl) && (b > fl) && (g * g > tol2 * a * b); }
+    }
+    need = __syncthreads_or(need);
+    if (!need) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
+  }
+  // cross_only: the two blocks were orthogonalised internally on earlier visits of this sweep, so only the
+  // 32 x 32 pairs (p in I, q in J) are visited: 32 rounds of 32 disjoint pairs (i, 32 + (i + r) % 32).
+  const int nrounds = cross_only ? BB : PB - 1;
+  for (int inner = 0; inner < max_inner; inner++) {
+    unsigned rot = 0;
+    for (int r = 0; r < nrounds; r++) {
+      int p, q;
+      if (cross_only) { p = wave * PW + (lane & (PW - 1)); q = BB + ((p + r) & (BB - 1)); }
+      else nd4_rr_pair(PB, r, wave * PW + (lane & (PW - 1)), p, q);
+      const double a = G[p][p], b = G[q][q], g = G[p][q];
+      const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
+      double c = 1.0, s = 0.0;                              // kept as (s, tau = tan(theta/2)): see svd.hip jac_step
+      if (go) {
+        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (b-a)/(2g), rewritten without the division by g
+        const double d = b - a, hh = 2.0 * g, rr = d * d + hh * hh;
+        const double root = rr * fast_rsqrt(rr);
+        const double tn = (((d < 0.0) != (g < 0.0)) ? -fabs(hh) : fabs(hh)) * fast_rcp(fabs(d) + root);
+        const double cc = fast_rsqrt(1.0 + tn * tn);
+        s = cc * tn;
+        c = s * fast_rcp(1.0 + cc);                        // c now holds tau = tan(theta/2)
+        relmax = fmax(relmax, (g * g) / (a * b));
+      }
+      rot += (unsigned)__popcll(__ballot(go && lane < PW));
+      // wave-uniform rotation parameters of this wave's 8 pairs (SGPRs)
+      double sk[PW], ck[PW]; int pk[PW], qk[PW];
+#define ND4_BC(K) sk[K] = bcast_d<K>(s); ck[K] = bcast_d<K>(c); pk[K] = bcast_i<K>(p); qk[K] = bcast_i<K>(q);
+      ND4_BC(0) ND4_BC(1)
+      if constexpr (PW > 2) { ND4_BC(2) ND4_BC(3) }
+#undef ND4_BC
+      // ---- row phase: rows p,q of G and of Q (lane = column). The 8 pairs touch disjoint rows, so all
+      // 32 reads are issued before the first write (the compiler cannot prove that by itself and would
+      // serialise read->fma->write eight times: this loop is LDS-latency bound, not bandwidth bound).
+      // An idle pair (s = 0) rewrites its rows unchanged.
+      {
+        double gp[PW], gq[PW], up[PW], uq[PW];
+#pragma unroll
+        for (int k = 0; k < PW; k++) { gp[k] = G[pk[k]][lane]; gq[k] = G[qk[k]][lane]; up[k] = Q[pk[k]][lane]; uq[k] = Q[qk[k]][lane]; }
+#pragma unroll
+        for (int k = 0; k < PW; k++) {
+          G[pk[k]][lane] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
+          G[qk[k]][lane] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
+          Q[pk[k]][lane] = up[k] - sk[k] * (uq[k] + ck[k] * up[k]);
+          Q[qk[k]][lane] = uq[k] + sk[k] * (up[k] - ck[k] * uq[k]);
+        }
+      }
+      __syncthreads();
+      // ---- column phase: columns p,q of G (lane = row) ----
+      {
+        double gp[PW], gq[PW];
+#pragma unroll
+        for (int k = 0; k < PW; k++) { gp[k] = G[lane][pk[k]]; gq[k] = G[lane][qk[k]]; }
+#pragma unroll
+        for (int k = 0; k < PW; k++) {
+          G[lane][pk[k]] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
+          G[lane][qk[k]] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) s_rot[wave] = rot;
+    __syncthreads();
+    unsigned tot = 0;
+    for (int w = 0; w < 32 / PW; w++) tot += s_rot[w];
+    __syncthreads();
+    total += tot;
+    if (tot == 0) break;
+  }
+  double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
+  if (total) for (int e = t; e < PB * PB; e += 2048 / PW) Qt[e] = Q[e / PB][e % PB];
+  // max over the wave of the largest cos^2 that triggered a rotation
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) relmax = fmax(relmax, __shfl_xor(relmax, off));
+  if (lane == 0 && relmax > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(relmax));
+  if (t == 0) {
+    flags[mat * sF_mat + pairIdx] = total ? 1 : 0;
+    if (total) atomicAdd(&st[mat].rotations, total);
+  }
+}
+
 __global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
                                                    const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
                                                    const int* __restrict__ flags, long sF_mat, int nchunks) {
@@ -326,6 +446,18 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
     } else {
       hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                          W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+      // ND4HIP_JAC_EIGEN8 = 0 (4 waves always) | 8 | 16; default: 16 waves when there are few workgroups
+      static const int e8 = getenv("ND4HIP_JAC_EIGEN8") ? atoi(getenv("ND4HIP_JAC_EIGEN8")) : -1;
+      const bool eight = e8 >= 0 ? e8 != 0 : ((long)batch * npairs <= 256);     // few workgroups: latency, not throughput, matters
+      if (eight && e8 != 8)
+        hipLaunchKernelGGL(jacb_eigen8<2>, dim3((unsigned)npairs, (unsigned)batch), dim3(1024), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
+                           (cross && step > 0) ? 1 : 0);
+      else if (eight)
+        hipLaunchKernelGGL(jacb_eigen8<4>, dim3((unsigned)npairs, (unsigned)batch), dim3(512), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
+                           (cross && step > 0) ? 1 : 0);
+      else
       hipLaunchKernelGGL(jacb_eigen<false>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
                          Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
                          (cross && step > 0) ? 1 : 0);
