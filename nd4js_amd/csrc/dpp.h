@@ -52,4 +52,19 @@ __device__ __forceinline__ int wave_min(int v) {
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// few-ulp reciprocal / reciprocal square root: hardware estimate + two Newton steps (~10 dependent instructions instead of the
+// ~35 of an IEEE division / ~30 of sqrt). For scalars on a latency chain whose consumers tolerate a few ulp.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
 }  // namespace nd4dpp

@@ -263,9 +263,13 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
       const double alpha = s_alpha;
       double beta = alpha, tau = 0.0, scale = 0.0;
       if (sigma != 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
+        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
+        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
+        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
+        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
+        beta = -copysign(nn * ri, alpha);
+        tau = (beta - alpha) * -copysign(ri, alpha);
+        scale = nd4dpp::fast_rcp(alpha - beta);
       }
       double vr[R], d[NB];
 #pragma unroll
@@ -432,9 +436,13 @@ __global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, i
       const double alpha = s_alpha;
       double beta = alpha, tau = 0.0, scale = 0.0;
       if (sigma != 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
+        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
+        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
+        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
+        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
+        beta = -copysign(nn * ri, alpha);
+        tau = (beta - alpha) * -copysign(ri, alpha);
+        scale = nd4dpp::fast_rcp(alpha - beta);
       }
       double vr[R], d[W8];
 #pragma unroll
@@ -599,9 +607,13 @@ __global__ __launch_bounds__(1024) void qr_panel_row4(double* __restrict__ Wm, i
       const double alpha = s_alpha;
       double beta = alpha, tau = 0.0, scale = 0.0;
       if (sigma != 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
+        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
+        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
+        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
+        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
+        beta = -copysign(nn * ri, alpha);
+        tau = (beta - alpha) * -copysign(ri, alpha);
+        scale = nd4dpp::fast_rcp(alpha - beta);
       }
       double vr[R], d[W8];
 #pragma unroll
