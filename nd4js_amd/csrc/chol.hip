@@ -15,6 +15,7 @@
 // LDL^T (src/la/ldl.js:47-201, no pivoting, D may be indefinite) shares the structure: ldl_diag / ldl_trsm keep the
 // UNSCALED panel W = L21 D11 next to L21 so that the trailing update is A22 -= W L21^T on the same tile-skipping GEMM.
 #include "nd4hip_internal.h"
+#include "dpp.h"
 
 namespace {
 
@@ -40,11 +41,18 @@ __global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, 
 #pragma unroll
   for (int j = 0; j < CB; j++) {
     if (j < nb) {
-      if (i == j) { const double d = sqrt(a[j]); bad = bad || (d != d); a[j] = d; s_col[j] = d; }
+      // pivot: lane j publishes the radicand; every lane forms 1/sqrt itself (rsq + two Newton steps, ~12 dependent
+      // instructions instead of sqrt ~30 + division ~35 on the column's critical path). d = x * rsqrt(x) and
+      // l = a / d = a * rsqrt(x) agree with sqrt / division to a few ulp (parity is to 1e-14 cond, the reference sums with
+      // Kahan anyway); a negative or NaN radicand still gives NaN (the flag); an exact 0 gives d = 0 and a * inf below it, which is
+      // a / 0 (+-Inf, or NaN for 0 / 0) exactly as in the reference.
+      if (i == j) s_col[j] = a[j];
       __syncthreads();
-      const double d = s_col[j];
+      const double x = s_col[j];
+      const double ri = nd4dpp::fast_rsqrt(x);
       __syncthreads();
-      if (i > j && i < nb) a[j] = a[j] / d;
+      if (i == j) { const double d = (x == 0.0) ? 0.0 : x * ri; bad = bad || (d != d); a[j] = d; }   // sqrt(0) = 0 like the reference
+      if (i > j && i < nb) a[j] = a[j] * ri;
       if (i < CB) s_col[i] = a[j];                 // column j of L (rows <= j hold their own earlier values: unused)
       __syncthreads();
       if (i > j && i < nb) {

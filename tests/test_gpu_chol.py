@@ -185,3 +185,10 @@ def test_ldl_errors_and_device_chain(la):
     xd = dev.ldl_solve(LDd, torch.from_numpy(y).cuda())
     assert np.array_equal(LDd.cpu().numpy(), la.ldl_decomp(S))
     assert relerr(xd.cpu().numpy(), np.linalg.solve(S, y)) <= 1e-11
+
+
+def test_cholesky_exact_zero_pivot_like_reference(la):
+    """an exactly singular PSD matrix whose zero pivot comes last: the reference returns L with a zero (no NaN, no error)"""
+    s = np.array([[1.0, 1.0], [1.0, 1.0]])
+    L = la.cholesky_decomp(s)
+    assert np.array_equal(L, oracle.cholesky_decomp(s)) and np.array_equal(L, [[1.0, 0.0], [1.0, 0.0]])
