@@ -168,13 +168,26 @@ function bcastGroupsN(lead, shapes, units) {
   }
   return groups;
 }
-function bcastLead(shapes, err) {            // common leading shape, NumPy rules
-  const nb = Math.max(...shapes.map(s => s.length)), lead = Array(nb).fill(1);
-  for (const sh of shapes)
-    for (let i = nb, j = sh.length; i-- > 0 && j-- > 0;)
-      if (lead[i] === 1) lead[i] = sh[j];
-      else if (lead[i] != sh[j] && sh[j] != 1) throw new Error(err);
+/* Common shape of right-aligned leading-axis lists under NumPy broadcasting (extent 1 stretches). */
+function bcastLead(shapes, err) {
+  const rank = shapes.reduce((r, sh) => Math.max(r, sh.length), 0), lead = new Array(rank).fill(1);
+  shapes.forEach(sh => {
+    const shift = rank - sh.length;
+    for (let d = 0; d < sh.length; d++) {
+      const have = lead[shift + d], want = sh[d];
+      if (want === 1 || want === have) continue;
+      if (have !== 1) throw new Error(err);
+      lead[shift + d] = want;
+    }
+  });
   return lead;
+}
+/* Shape of matmul2 for operand shapes sA, sB (plain arrays / Int32Arrays): [result shape, I, K, J]. */
+function productShape(sA, sB, mismatch) {
+  const I = sA[sA.length - 2], K = sA[sA.length - 1], J = sB[sB.length - 1];
+  if (sB[sB.length - 2] != K) throw new Error(mismatch);
+  const lead = bcastLead([Array.from(sA).slice(0, -2), Array.from(sB).slice(0, -2)], 'Shapes are not broadcast-compatible.');
+  return [lead.concat([I, J]), I, K, J];
 }
 
 function makeLa(NDA, fallback) {
@@ -206,8 +219,7 @@ function makeLa(NDA, fallback) {
     a = asarray(a); b = asarray(b);
     if (a.ndim < 2) throw new Error('A must be at least 2D.');
     if (b.ndim < 2) throw new Error('B must be at least 2D.');
-    const I = a.shape[a.ndim - 2], K = a.shape[a.ndim - 1], J = b.shape[b.ndim - 1];
-    if (b.shape[b.ndim - 2] != K) throw new Error('The last dimension of A and the 2nd to last dimension of B do not match.');
+    const [shape, I, K, J] = productShape(a.shape, b.shape, 'The last dimension of A and the 2nd to last dimension of B do not match.');
     const da = dtypeOf(a), db = dtypeOf(b);
     // GPU path: at least one float64 operand and the other float64/int32 (result dtype float64, matmul.js:119);
     // int32 x int32 (wrapping Int32Array result), float32, complex128, object -> the host's own function
@@ -215,13 +227,7 @@ function makeLa(NDA, fallback) {
       if (fallback && fallback.matmul2) return fallback.matmul2(a, b);
       throw new Error(`nd4hip.matmul2: dtype pair (${da}, ${db}) is not accelerated and no host nd4js was installed.`);
     }
-    const ndim = Math.max(a.ndim, b.ndim), shape = Int32Array.from({length: ndim}, () => 1);
-    shape[ndim - 2] = I; shape[ndim - 1] = J;
-    for (const arr of [a, b])
-      for (let i = ndim - 2, j = arr.ndim - 2; i-- > 0 && j-- > 0;)
-        if (1 === shape[i]) shape[i] = arr.shape[j];
-        else if (shape[i] != arr.shape[j] && arr.shape[j] != 1) throw new Error('Shapes are not broadcast-compatible.');
-    const lead = Array.from(shape.subarray(0, ndim - 2));
+    const lead = shape.slice(0, -2);
     const dev = isDev(a) || isDev(b), temps = [];
     const A = opF64(a, dev, temps), B = opF64(b, dev, temps), C = alloc(dev, shape.reduce((m, n) => m * n, 1));
     for (const [cnt, offA, sA, offB, sB, offC] of bcastGroups(lead, a.shape.subarray(0, a.ndim - 2), b.shape.subarray(0, b.ndim - 2), I * K, K * J))
@@ -230,44 +236,33 @@ function makeLa(NDA, fallback) {
     return wrap(dev, shape, C);
   };
 
-  la.matmul = function matmul(...matrices) {            // chain ordering stays on the host (matmul.js:150-236)
-    matrices = matrices.map(asarray);
-    if (matrices.length == 1) return matrices[0];
-    if (matrices.length == 2) return la.matmul2(...matrices);
-    const nOps = (sA, sB) => {
-      const I = sA[sA.length - 2], K = sA[sA.length - 1], J = sB[sB.length - 1];
-      if (sB[sB.length - 2] != K) throw new Error('Shape mismatch.');
-      const ndim = Math.max(sA.length, sB.length), shape = Int32Array.from({length: ndim}, () => 1);
-      shape[ndim - 2] = I; shape[ndim - 1] = J;
-      for (const shp of [sA, sB])
-        for (let i = ndim - 2, j = shp.length - 2; i-- > 0 && j-- > 0;)
-          if (1 === shape[i]) shape[i] = shp[j];
-          else if (shape[i] != shp[j] && shp[j] != 1) throw new Error('Shapes are not broadcast-compatible.');
-      return [shape.reduce((x, y) => x * y, 1) * K, shape];
-    };
-    const n = matrices.length, op = Array.from({length: n}, () => []);
-    for (let i = 0; i < n; i++) op[i][i] = [0, matrices[i].shape];
-    for (let len = 2; len <= n; len++)
-      for (let i = 0; i <= n - len; i++) {
-        let minF = Infinity, minS;
-        for (let j = 1; j < len; j++) {
-          const [lf, ls] = op[i][i + j - 1], [rf, rs] = op[i + j][i + len - 1];
-          let [f, s] = nOps(ls, rs); f += lf + rf;
-          if (f < minF) { minF = f; minS = s; }
+  /* Matrix-chain ordering (CLRS 15.2) with broadcast leading axes; one product costs numel(result)*K, which is how
+     matmul.js:150-236 counts. cut[lo][hi] = last operand of the left factor of the cheapest split of lo..hi, the first
+     among equals. A sub-chain's shape does not depend on its split, so one shape per span is kept. */
+  la._chain_plan = function chainPlan(shapes) {
+    const n = shapes.length, table = init => shapes.map(() => new Array(n).fill(init));
+    const span = table(null), cost = table(0), cut = table(-1);
+    shapes.forEach((sh, k) => { span[k][k] = Array.from(sh); });
+    for (let width = 1; width < n; width++)
+      for (let lo = 0, hi = width; hi < n; lo++, hi++) {
+        let best = Infinity;
+        for (let mid = lo; mid < hi; mid++) {
+          const [shp, , K] = productShape(span[lo][mid], span[mid + 1][hi], 'Shape mismatch.');
+          const c = shp.reduce((v, e) => v * e, 1) * K + (cost[lo][mid] + cost[mid + 1][hi]);
+          if (c < best) { best = c; cut[lo][hi] = mid; span[lo][hi] = shp; }
         }
-        if (minS === undefined) throw new Error('Integer overflow (too many FLOPs).');
-        op[i][i + len - 1] = [minF, minS];
+        if (cut[lo][hi] < 0) throw new Error('Integer overflow (too many FLOPs).');
+        cost[lo][hi] = best;
       }
-    const product = (from, to) => {
-      if (from == to) return matrices[from];
-      let minF = Infinity, minI;
-      for (let i = from; i < to; i++) {
-        const f = nOps(op[from][i][1], op[i + 1][to][1])[0] + op[from][i][0] + op[i + 1][to][0];
-        if (f < minF) { minF = f; minI = i; }
-      }
-      return la.matmul2(product(from, minI), product(minI + 1, to));
-    };
-    return product(0, n - 1);
+    return cut;
+  };
+  la.matmul = function matmul(...matrices) {            // contract of matmul.js:150-236; the ordering stays on the host
+    const ms = matrices.map(asarray);
+    if (ms.length === 1) return ms[0];
+    if (ms.length === 2) return la.matmul2(ms[0], ms[1]);
+    const cut = la._chain_plan(ms.map(m => m.shape));
+    const evaluate = (lo, hi) => lo === hi ? ms[lo] : la.matmul2(evaluate(lo, cut[lo][hi]), evaluate(cut[lo][hi] + 1, hi));
+    return evaluate(0, ms.length - 1);
   };
 
   la.qr_decomp = function qr_decomp(A) {

@@ -84,52 +84,64 @@ def matmul2(a, b, device=None):
     return c
 
 
-def _n_ops(sa, sb):
-    I, K = sa[-2:]
-    J = sb[-1]
-    if sb[-2] != K:
+def _product_shape(sa, sb):
+    """Shape of matmul2 of operands shaped `sa`, `sb` (leading axes NumPy-broadcast) and its inner extent K."""
+    if sb[-2] != sa[-1]:
         raise ValueError("Shape mismatch.")
-    try:
-        lead = np.broadcast_shapes(tuple(sa[:-2]), tuple(sb[:-2]))
-    except ValueError:
+    la_, lb_ = tuple(sa[:-2]), tuple(sb[:-2])
+    rank = max(len(la_), len(lb_))
+    la_, lb_ = (1,) * (rank - len(la_)) + la_, (1,) * (rank - len(lb_)) + lb_
+    if any(x != y and x != 1 and y != 1 for x, y in zip(la_, lb_)):
         raise ValueError("Shapes are not broadcast-compatible.")
-    shape = tuple(lead) + (I, J)
-    return int(np.prod(shape, dtype=np.int64)) * K, shape
+    return tuple(y if x == 1 else x for x, y in zip(la_, lb_)) + (sa[-2], sb[-1]), sa[-1]
 
 
-def matmul(*matrices, device=None):
-    """Matrix-chain product in the FLOP-optimal order (matmul.js:150-236)."""
+def chain_plan(shapes):
+    """Matrix-chain ordering (CLRS 15.2) generalised to broadcast leading axes: the cost of one product is
+    numel(result)·K multiply-adds, as matmul.js:150-236 counts it. Returns `cut` with cut[lo][hi] = last operand
+    of the left factor of the cheapest split of operands lo..hi (the first one among equals, in double
+    arithmetic like the reference's Number). The shape of a sub-chain does not depend on how it is split, so one
+    shape per span is enough."""
+    n = len(shapes)
+    shape = [[None] * n for _ in range(n)]
+    cost = [[0.0] * n for _ in range(n)]
+    cut = [[-1] * n for _ in range(n)]
+    for k in range(n):
+        shape[k][k] = tuple(shapes[k])
+    for width in range(1, n):
+        for lo in range(n - width):
+            hi = lo + width
+            best = float("inf")
+            for mid in range(lo, hi):
+                shp, K = _product_shape(shape[lo][mid], shape[mid + 1][hi])
+                numel = 1.0
+                for e in shp:
+                    numel *= e
+                c = numel * K + (cost[lo][mid] + cost[mid + 1][hi])
+                if c < best:
+                    best, cut[lo][hi], shape[lo][hi] = c, mid, shp
+            if cut[lo][hi] < 0:
+                raise ValueError("Integer overflow (too many FLOPs).")
+            cost[lo][hi] = best
+    return cut
+
+
+def matmul(*matrices, device=None, _matmul2=None):
+    """Product of a chain of matrices in the FLOP-optimal order (contract of matmul.js:150-236): one operand
+    is returned as is, two go straight to matmul2, longer chains are parenthesised by `chain_plan`."""
     ms = [_asarray(m, "matmul(...)") for m in matrices]
+    mm = _matmul2 or (lambda x, y: matmul2(x, y, device))
     if len(ms) == 1:
         return ms[0]
     if len(ms) == 2:
-        return matmul2(ms[0], ms[1], device)
-    n = len(ms)
-    op = [[None] * n for _ in range(n)]
-    for i in range(n):
-        op[i][i] = (0, ms[i].shape)
-    for length in range(2, n + 1):
-        for i in range(0, n - length + 1):
-            best = None
-            for j in range(1, length):
-                lf, ls = op[i][i + j - 1]
-                rf, rs = op[i + j][i + length - 1]
-                f, shp = _n_ops(ls, rs)
-                f += lf + rf
-                if best is None or f < best[0]:
-                    best = (f, shp)
-            op[i][i + length - 1] = best
+        return mm(ms[0], ms[1])
+    cut = chain_plan([m.shape for m in ms])
 
-    def product(lo, hi):
+    def evaluate(lo, hi):
         if lo == hi:
             return ms[lo]
-        best, idx = None, None
-        for i in range(lo, hi):
-            f = _n_ops(op[lo][i][1], op[i + 1][hi][1])[0] + op[lo][i][0] + op[i + 1][hi][0]
-            if best is None or f < best:
-                best, idx = f, i
-        return matmul2(product(lo, idx), product(idx + 1, hi), device)
-    return product(0, n - 1)
+        return mm(evaluate(lo, cut[lo][hi]), evaluate(cut[lo][hi] + 1, hi))
+    return evaluate(0, len(ms) - 1)
 
 
 def qr_decomp(A, device=None):

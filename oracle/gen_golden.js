@@ -13,6 +13,8 @@
  *   node oracle/gen_golden.js c3               # 2048^2 QR + LU samples  (~20 s)
  *   node oracle/gen_golden.js c4               # 2048^2 SVD sv + samples (~70 s)
  *   node oracle/gen_golden.js c5 [stride]      # 512^2 SVDs of every `stride`-th batch member
+ *   node oracle/gen_golden.js chain            # matmul(...ms) chains: hand cases of matmul_test.js:32-79 + seeded 3-5 operand chains
+ *   node oracle/gen_golden.js c3b              # 4096^2 QR + LU (rows beyond the 2048-row register panels) (~3 min)
  */
 'use strict';
 const fs = require('fs'), path = require('path');
@@ -361,6 +363,54 @@ if (what === 'bidiag') {
   caseBd('bidiag_sparse_sq_30', 202, [30, 30], true);
   caseBd('bidiag_sparse_vert', 203, [33, 12], true);
   caseBd('bidiag_sq_130', 204, [130, 130]);
+}
+
+if (what === 'chain') {
+  /* SURVEY §8a A2: matmul(...ms) (matmul.js:150-236). Hand cases = the three value-pinned cases of the reference's own
+     test (matmul_test.js:32-79), stored as float64 inputs + the reference's result; seeded chains exercise the
+     FLOP-optimal ordering with NumPy-broadcast leading axes. */
+  const numel = sh => sh.reduce((x, y) => x * y, 1);
+  const hand = (name, mats) => {
+    const ms = mats.map(([shape, vals]) => NDA(shape, Float64Array.from(vals)));
+    const C = ms.length === 2 ? nd.la.matmul2(...ms) : nd.la.matmul(...ms);
+    const t = {C: [Float64Array.from(C.data), Array.from(C.shape)]};
+    ms.forEach((m, k) => { t['M' + k] = [m.data, Array.from(m.shape)]; });
+    record(name, {op: 'matmul', hand: true, n: ms.length, shapes: mats.map(m => m[0])}, t);
+  };
+  hand('chain_hand_2x1_1x3', [[[2, 1], [1, 2]], [[1, 3], [30, 40, 50]]]);
+  hand('chain_hand_2x3_3x2', [[[2, 3], [1, 2, 3, 4, 5, 6]], [[3, 2], [70, 80, 90, 100, 110, 120]]]);
+  hand('chain_hand_1x4_4x3_3x2', [[[1, 4], [1, 2, 3, 4]], [[4, 3], [11, 12, 13, 21, 22, 23, 31, 32, 33, 41, 42, 43]], [[3, 2], [5, 6, 7, 8, 9, 10]]]);
+  const seeded = (name, seed0, shapes) => {
+    const ms = shapes.map((sh, k) => NDA(sh, fill(seed0 + k, numel(sh))));
+    const C = nd.la.matmul(...ms);
+    record(name, {op: 'matmul', seed0, shapes, shapeC: Array.from(C.shape)}, {C: [C.data, Array.from(C.shape)]});
+  };
+  seeded('chain_3_small_mid', 301, [[30, 4], [4, 50], [50, 6]]);                 // (AB)C vs A(BC): right first
+  seeded('chain_3_left_first', 311, [[5, 60], [60, 7], [7, 80]]);
+  seeded('chain_4', 321, [[40, 10], [10, 33], [33, 5], [5, 64]]);
+  seeded('chain_5', 331, [[12, 31], [31, 9], [9, 45], [45, 3], [3, 27]]);
+  seeded('chain_3_bcast', 341, [[3, 1, 8, 20], [2, 20, 6], [6, 11]]);            // leading axes change the costs
+  seeded('chain_4_bcast', 351, [[7, 15], [4, 1, 15, 2], [3, 2, 40], [1, 3, 40, 9]]);
+  seeded('chain_5_bcast', 361, [[2, 9, 14], [14, 14], [2, 14, 3], [3, 22], [1, 22, 5]]);
+  seeded('chain_ties', 371, [[16, 16], [16, 16], [16, 16], [16, 16]]);           // every order costs the same: first split wins
+  seeded('chain_1', 381, [[6, 7]]);
+  seeded('chain_vec', 391, [[1, 33], [33, 33], [33, 1]]);
+}
+
+if (what === 'c3b') {
+  /* 4096^2 QR and LU: sizes whose panels take the >2048-row register-panel variants on the GPU */
+  const N = 4096, a = fill(17, N * N);
+  let t = Date.now();
+  const [Q, R] = nd.la.qr_decomp(NDA([N, N], a)); const tqr = (Date.now() - t) / 1e3;
+  console.log('qr', tqr);
+  t = Date.now();
+  const [LU, P] = nd.la.lu_decomp(NDA([N, N], a)); const tlu = (Date.now() - t) / 1e3;
+  const dR = new Float64Array(N); for (let i = 0; i < N; i++) dR[i] = R.data[i * N + i];
+  const [qi, qv] = sample(Q.data, 4096, 1701), [ri, rv] = sample(R.data, 4096, 1702), [li, lv] = sample(LU.data, 4096, 1703);
+  record('c3b_qr4096', {op: 'qr_decomp', seed: 17, shape: [N, N], froQ: fro(Q.data), froR: fro(R.data), ref_seconds: tqr},
+    {diagR: [dR, [N]], Qidx: [qi, [4096]], Qval: [qv, [4096]], Ridx: [ri, [4096]], Rval: [rv, [4096]]});
+  record('c3b_lu4096', {op: 'lu_decomp', seed: 17, shape: [N, N], froLU: fro(LU.data), ref_seconds: tlu},
+    {P: [P.data, [N]], LUidx: [li, [4096]], LUval: [lv, [4096]]});
 }
 
 if (what === 'c2') {

@@ -57,6 +57,14 @@ if (mode === 'cpu') {
                      () => la.lu_decomp(fill(1, [4, 4])), () => la.svd_decomp(fill(1, [4, 4]))])
       assert.throws(f, /no HIP device/);          // loud failure, no CPU fallback
   }
+  assert.throws(() => la.matmul(fill(1, [2, 3]), fill(2, [4, 2]), fill(3, [2, 2])), /Shape mismatch\./);
+  assert.throws(() => la.matmul(fill(1, [2, 2, 3]), fill(2, [3, 3, 2]), fill(3, [2, 2])), /broadcast-compatible/);
+  { const one = fill(1, [3, 4]); assert.strictEqual(la.matmul(one), one); }
+  if (process.argv[3]) {            // chain plans for the golden chain shapes, compared by the Python test with la.chain_plan
+    const man = JSON.parse(fs.readFileSync(path.join(process.argv[3], 'manifest.json'))).cases, plans = {};
+    for (const [name, m] of Object.entries(man)) if (m.op === 'matmul' && m.shapes.length > 2) plans[name] = la._chain_plan(m.shapes);
+    console.log('PLANS ' + JSON.stringify(plans));
+  }
   console.log('node cpu checks ok');
 }
 
@@ -69,6 +77,16 @@ if (mode === 'install') {
   assert.strictEqual(typeof nd2.la.det, 'function'); // everything else is still there
   if (la.device_count() === 0)
     assert.throws(() => nd2.la.matmul2(new nd.NDArray(Int32Array.of(2, 2), Float64Array.of(1, 2, 3, 4)), a), /no HIP device/);
+  { // float32 operands go to the reference's matmul2 through the fallback: the chain ORDER is then the only thing that
+    // can make la.matmul differ from the reference's matmul (float32 rounding after every product is order-sensitive)
+    const f32 = (seed, shape) => { const x = fill(seed, shape); return new nd.NDArray(Int32Array.from(shape), Float32Array.from(x.data)); };
+    for (const shapes of [[[30, 4], [4, 50], [50, 6]], [[5, 60], [60, 7], [7, 80]], [[40, 10], [10, 33], [33, 5], [5, 64]],
+                          [[3, 1, 8, 20], [2, 20, 6], [6, 11]], [[2, 9, 14], [14, 14], [2, 14, 3], [3, 22], [1, 22, 5]], [[16, 16], [16, 16], [16, 16], [16, 16]]]) {
+      const ms = shapes.map((sh, k) => f32(900 + k, sh)), mine = nd2.la.matmul(...ms), ref = nd.la.matmul(...ms);
+      assert.ok(mine.data instanceof Float32Array); assert.deepStrictEqual(Array.from(mine.shape), Array.from(ref.shape));
+      for (let i = 0; i < ref.data.length; i++) assert.ok(mine.data[i] === ref.data[i], 'chain order differs from the reference');
+    }
+  }
   console.log('node install checks ok');
 }
 
@@ -149,6 +167,9 @@ if (mode === 'gpu') {
     assert.ok(relerr(U.data, npy('hess_17', 'U').data) <= 1e-12 && relerr(H.data, npy('hess_17', 'H').data) <= 1e-12); }
   { for (const c of ['bidiag_sq_17', 'bidiag_vert_20x7', 'bidiag_horiz_7x20']) { const m = man[c], [U, B, V] = la.bidiag_decomp(fill(m.seed, m.shape));
       for (const [x, k] of [[U, 'U'], [B, 'B'], [V, 'V']]) { const ref = npy(c, k); assert.deepStrictEqual(Array.from(x.shape), ref.shape); assert.ok(relerr(x.data, ref.data) <= 1e-11, c + ' ' + k); } } }
-  { const chain = la.matmul(fill(3, [8, 2]), fill(4, [2, 9]), fill(5, [9, 3])); assert.deepStrictEqual(Array.from(chain.shape), [8, 3]); }
+  for (const c of ['chain_4_bcast', 'chain_5', 'chain_hand_1x4_4x3_3x2']) {    // matmul(...ms) against the reference's own results
+    const m = man[c], ref = npy(c, 'C');
+    const ms = m.hand ? m.shapes.map((sh, k) => { const x = npy(c, 'M' + k); return new la.NDArray(Int32Array.from(x.shape), x.data); }) : m.shapes.map((sh, k) => fill(m.seed0 + k, sh));
+    const C = la.matmul(...ms); assert.deepStrictEqual(Array.from(C.shape), ref.shape); assert.ok(relerr(C.data, ref.data) <= 1e-13, c); }
   console.log('node gpu checks ok');
 }

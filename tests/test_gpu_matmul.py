@@ -63,10 +63,26 @@ def test_batched_and_broadcast_vs_oracle(la):
         assert c.shape == ref.shape and relerr(c, ref) <= TIGHT
 
 
-def test_matmul_chain_matches_pairwise(la):
-    ms = [rng.matrix(500 + i, *s) for i, s in enumerate([(30, 5), (5, 60), (60, 8), (8, 40)])]
-    ref = ms[0] @ ms[1] @ ms[2] @ ms[3]
-    assert relerr(la.matmul(*ms), ref) <= 1e-12
+def chain_operands(g):
+    if g.meta.get("hand"):
+        return [g["M%d" % k] for k in range(g.n)]
+    return [rng.matrix(g.seed0 + k, *s) for k, s in enumerate(g.shapes)]
+
+
+@pytest.mark.parametrize("name", golden_cases(op="matmul"))
+def test_matmul_chain_vs_reference_golden(la, golden, name):
+    """matmul(...ms) (matmul.js:150-236) against the reference's own results: the three value-pinned cases of
+    matmul_test.js:32-79 and seeded 1-5 operand chains with broadcast leading axes."""
+    g = golden(name)
+    c = la.matmul(*chain_operands(g))
+    ref = g["C"]
+    assert c.shape == ref.shape
+    assert relerr(c, ref) <= TIGHT
+
+
+def test_matmul_chain_hand_case_exact(la):
+    assert np.array_equal(la.matmul([[1, 2, 3, 4]], [[11, 12, 13], [21, 22, 23], [31, 32, 33], [41, 42, 43]], [[5, 6], [7, 8], [9, 10]]),
+                          [[6760.0, 7720.0]])          # matmul_test.js:64-79
 
 
 def test_inputs_untouched_and_zero_extent(la):

@@ -22,7 +22,17 @@ def run(*args):
 
 @needs_node
 def test_js_wrapper_validation_and_loud_failure():
-    assert "node cpu checks ok" in run("cpu")
+    out = run("cpu", GOLDEN)
+    assert "node cpu checks ok" in out
+    # the JS chain planner and the Python one choose the same parenthesisation for every golden chain
+    import json
+    from nd4js_amd import la
+    plans = json.loads([ln for ln in out.splitlines() if ln.startswith("PLANS ")][0][6:])
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(plans) >= 8
+    for name, cut in plans.items():
+        assert cut == la.chain_plan(cases[name]["shapes"]), name
 
 
 @needs_node
