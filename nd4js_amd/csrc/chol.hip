@@ -44,14 +44,16 @@ __global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, 
       // pivot: lane j publishes the radicand; every lane forms 1/sqrt itself (rsq + two Newton steps, ~12 dependent
       // instructions instead of sqrt ~30 + division ~35 on the column's critical path). d = x * rsqrt(x) and
       // l = a / d = a * rsqrt(x) agree with sqrt / division to a few ulp (parity is to 1e-14 cond, the reference sums with
-      // Kahan anyway); a negative or NaN radicand still gives NaN (the flag); an exact 0 gives d = 0 and a * inf below it, which is
-      // a / 0 (+-Inf, or NaN for 0 / 0) exactly as in the reference.
+      // Kahan anyway); a negative or NaN radicand still gives NaN (the flag). The Newton steps turn rsq(0) = inf and rsq(inf) = 0
+      // into NaN, so those two radicands take the reference's own formulas (cholesky.js:40-41): d = sqrt(x), l = a / d, i.e.
+      // d = +-0 with +-Inf (NaN for 0 / 0) below it, and d = Inf with zeros below it. The branch is wave-uniform.
       if (i == j) s_col[j] = a[j];
       __syncthreads();
       const double x = s_col[j];
-      const double ri = nd4dpp::fast_rsqrt(x);
+      double ri = nd4dpp::fast_rsqrt(x), d = x * ri;
+      if (__builtin_expect(x == 0.0 || __builtin_isinf(x), 0)) { d = sqrt(x); ri = 1.0 / d; }
       __syncthreads();
-      if (i == j) { const double d = (x == 0.0) ? 0.0 : x * ri; bad = bad || (d != d); a[j] = d; }   // sqrt(0) = 0 like the reference
+      if (i == j) { bad = bad || (d != d); a[j] = d; }
       if (i > j && i < nb) a[j] = a[j] * ri;
       if (i < CB) s_col[i] = a[j];                 // column j of L (rows <= j hold their own earlier values: unused)
       __syncthreads();

@@ -15,6 +15,8 @@ struct DevBuf {
   nd4hip_handle* h = nullptr;
   int slot = -1;
   ~DevBuf() {
+    // error path of a host-pointer call: its async copies / kernels may still be using the block
+    if (h && h->host_io_pending) { (void)hipStreamSynchronize(h->stream); h->host_io_pending = false; }
     if (slot >= 0) h->stage[(size_t)slot].in_use = false;
     else if (p) (void)hipFree(p);
   }
@@ -43,11 +45,19 @@ struct DevBuf {
 };
 
 int h2d(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  h->host_io_pending = true;
   if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
   return 0;
 }
 int d2h(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
+  h->host_io_pending = true;
   if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+// end of a host-pointer call (or a mid-call read-back): everything queued on the stream has landed
+int host_sync(nd4hip_handle* h) {
+  ND4_HIP(hipStreamSynchronize(h->stream));
+  h->host_io_pending = false;
   return 0;
 }
 constexpr size_t D = sizeof(double);
@@ -63,6 +73,7 @@ constexpr int64_t ND4_CHUNK = 32768;
 extern "C" int nd4hip_dgemm_batched_dev(nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
                                         const double* A, int64_t strideA, const double* B, int64_t strideB, double* C) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && I >= 0 && K >= 0 && J >= 0, "nd4hip_dgemm_batched: negative extent");
   ND4_CHECK_ARG(strideA == 0 || strideA >= I * K, "nd4hip_dgemm_batched: strideA must be 0 or >= I*K");
   ND4_CHECK_ARG(strideB == 0 || strideB >= K * J, "nd4hip_dgemm_batched: strideB must be 0 or >= K*J");
@@ -79,9 +90,9 @@ extern "C" int nd4hip_dgemm_batched_dev(nd4hip_handle* h, int64_t batch, int64_t
 extern "C" int nd4hip_dgemm_batched(nd4hip_handle* h, int64_t batch, int64_t I, int64_t K, int64_t J,
                                     const double* A, int64_t strideA, const double* B, int64_t strideB, double* C) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && I >= 0 && K >= 0 && J >= 0, "nd4hip_dgemm_batched: negative extent");
   if (batch == 0 || I == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nA = (size_t)(strideA ? (batch - 1) * strideA + I * K : I * K);
   const size_t nB = (size_t)(strideB ? (batch - 1) * strideB + K * J : K * J);
   const size_t nC = (size_t)(batch * I * J);
@@ -90,7 +101,7 @@ extern "C" int nd4hip_dgemm_batched(nd4hip_handle* h, int64_t batch, int64_t I, 
   ND4_TRY(h2d(h, dA.p, A, nA * D)); ND4_TRY(h2d(h, dB.p, B, nB * D));
   ND4_TRY(nd4hip_dgemm_batched_dev(h, batch, I, K, J, (const double*)dA.p, strideA, (const double*)dB.p, strideB, (double*)dC.p));
   ND4_TRY(d2h(h, C, dC.p, nC * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
@@ -98,6 +109,7 @@ extern "C" int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int
                                    double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
                                    double beta, double* C, int64_t ldc) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_ex: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "nd4hip_dgemm_ex: negative extent");
   ND4_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "nd4hip_dgemm_ex: leading dimension too small");
   if (M == 0 || N == 0) return 0;
@@ -107,6 +119,7 @@ extern "C" int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int
 // ------------------------------------------------------------------------------------ LU
 extern "C" int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && LU && P, "nd4hip_dgetrf_batched: NULL pointer");
@@ -115,16 +128,16 @@ extern "C" int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 }
 extern "C" int nd4hip_dgetrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)(batch * N * N);
   DevBuf dA, dLU, dP;
   ND4_TRY(dA.alloc(h, n * D)); ND4_TRY(dLU.alloc(h, n * D)); ND4_TRY(dP.alloc(h, (size_t)(batch * N) * 4));
   ND4_TRY(h2d(h, dA.p, A, n * D));
   ND4_TRY(nd4hip_dgetrf_batched_dev(h, batch, N, (const double*)dA.p, (double*)dLU.p, (int32_t*)dP.p));
   ND4_TRY(d2h(h, LU, dLU.p, n * D)); ND4_TRY(d2h(h, P, dP.p, (size_t)(batch * N) * 4));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
@@ -139,6 +152,7 @@ int copy_rhs(nd4hip_handle* h, int64_t batch, int64_t rows, int64_t J, const dou
 extern "C" int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
                                          const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dgetrs_batched: negative extent");
   ND4_CHECK_ARG((strideLU == 0 || strideLU >= N * N) && (strideP == 0 || strideP >= N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dgetrs_batched: a stride must be 0 or at least the size of one operand");
@@ -150,9 +164,9 @@ extern "C" int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dgetrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t strideLU,
                                      const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dgetrs_batched: negative extent");
   if (batch == 0 || N == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nLU = (size_t)(strideLU ? (batch - 1) * strideLU + N * N : N * N);
   const size_t nP = (size_t)(strideP ? (batch - 1) * strideP + N : N);
   const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
@@ -163,13 +177,14 @@ extern "C" int nd4hip_dgetrs_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   ND4_TRY(nd4hip_dgetrs_batched_dev(h, batch, N, J, (const double*)dLU.p, strideLU, (const int32_t*)dP.p, strideP,
                                     (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 extern "C" int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
                                         const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dtrsm_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && J >= 0, "nd4hip_dtrsm_batched: negative extent");
   ND4_CHECK_ARG((strideT == 0 || strideT >= M * M) && (strideY == 0 || strideY >= M * J),
                 "nd4hip_dtrsm_batched: a stride must be 0 or at least the size of one operand");
@@ -182,9 +197,9 @@ extern "C" int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_di
 extern "C" int nd4hip_dtrsm_batched(nd4hip_handle* h, int upper, int unit_diag, int64_t batch, int64_t M, int64_t J,
                                     const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dtrsm_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && J >= 0, "nd4hip_dtrsm_batched: negative extent");
   if (batch == 0 || M == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nT = (size_t)(strideT ? (batch - 1) * strideT + M * M : M * M);
   const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + M * J : M * J);
   const size_t nX = (size_t)(batch * M * J);
@@ -193,7 +208,7 @@ extern "C" int nd4hip_dtrsm_batched(nd4hip_handle* h, int upper, int unit_diag, 
   ND4_TRY(h2d(h, dT.p, T, nT * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
   ND4_TRY(nd4hip_dtrsm_batched_dev(h, upper, unit_diag, batch, M, J, (const double*)dT.p, strideT, (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
@@ -202,6 +217,7 @@ extern "C" int nd4hip_dqrls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t
                                         const double* Q, int64_t strideQ, const double* R, int64_t strideR,
                                         const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dqrls_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dqrls_batched: negative extent");
   ND4_CHECK_ARG(I <= N, "qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.");      // qr.js:209
   ND4_CHECK_ARG((strideQ == 0 || strideQ >= N * M) && (strideR == 0 || strideR >= M * I) && (strideY == 0 || strideY >= N * J),
@@ -217,9 +233,9 @@ extern "C" int nd4hip_dqrls_batched(nd4hip_handle* h, int64_t batch, int64_t N, 
                                     const double* Q, int64_t strideQ, const double* R, int64_t strideR,
                                     const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dqrls_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dqrls_batched: negative extent");
   if (batch == 0 || I == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nQ = (size_t)(strideQ ? (batch - 1) * strideQ + N * M : N * M);
   const size_t nR = (size_t)(strideR ? (batch - 1) * strideR + M * I : M * I);
   const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
@@ -232,7 +248,7 @@ extern "C" int nd4hip_dqrls_batched(nd4hip_handle* h, int64_t batch, int64_t N, 
   ND4_TRY(nd4hip_dqrls_batched_dev(h, batch, N, M, I, J, (const double*)dQ.p, strideQ, (const double*)dR.p, strideR,
                                    (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
@@ -240,6 +256,7 @@ extern "C" int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                                          const double* U, int64_t strideU, const double* sv, int64_t strideSv,
                                          const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dsvdls_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dsvdls_batched: negative extent");
   ND4_CHECK_ARG((strideU == 0 || strideU >= N * M) && (strideSv == 0 || strideSv >= M) && (strideV == 0 || strideV >= M * I) &&
                 (strideY == 0 || strideY >= N * J), "nd4hip_dsvdls_batched: a stride must be 0 or at least the size of one operand");
@@ -255,6 +272,7 @@ extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N,
                                      const double* U, int64_t strideU, const double* sv, int64_t strideSv,
                                      const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dsvdls_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dsvdls_batched: negative extent");
   if (batch == 0 || I == 0 || J == 0) return 0;
   const size_t nU = (size_t)(strideU ? (batch - 1) * strideU + N * M : N * M);
@@ -266,7 +284,6 @@ extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N,
     ND4_CHECK_ARG(sv != nullptr, "nd4hip_dsvdls_batched: NULL pointer");
     for (size_t i = 0; i < nS; i++) ND4_CHECK_ARG(std::isfinite(sv[i]), "svd_solve(): NaN or Infinity encountered.");   // svd.js:171-172
   }
-  ND4_HIP(hipSetDevice(h->device));
   DevBuf dU, dS, dV, dY, dX;
   ND4_TRY(dU.alloc(h, nU * D)); ND4_TRY(dS.alloc(h, nS * D)); ND4_TRY(dV.alloc(h, nV * D)); ND4_TRY(dY.alloc(h, nY * D)); ND4_TRY(dX.alloc(h, nX * D));
   if (nU) ND4_TRY(h2d(h, dU.p, U, nU * D));
@@ -276,13 +293,14 @@ extern "C" int nd4hip_dsvdls_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   ND4_TRY(nd4hip_dsvdls_batched_dev(h, batch, N, M, I, J, (const double*)dU.p, strideU, (const double*)dS.p, strideSv,
                                     (const double*)dV.p, strideV, (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // ---- Cholesky: cholesky_decomp (cholesky.js:51-71), cholesky_solve (:74-150)   
 extern "C" int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dpotrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(S && L, "nd4hip_dpotrf_batched: NULL pointer");
@@ -296,28 +314,29 @@ extern "C" int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_
   ND4_TRY(nd4_pinned(h, sizeof(int) * (size_t)batch, &hp));
   int* host = static_cast<int*>(hp);
   ND4_HIP(hipMemcpyAsync(host, flags, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, h->stream));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   for (int64_t b = 0; b < batch; b++)
     if (host[b]) { nd4_set_error("Matrix contains NaNs or is (near) singular."); return ND4HIP_ERR_SINGULAR; }
   return 0;
 }
 extern "C" int nd4hip_dpotrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dpotrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)(batch * N * N);
   DevBuf dS, dL;
   ND4_TRY(dS.alloc(h, n * D)); ND4_TRY(dL.alloc(h, n * D));
   ND4_TRY(h2d(h, dS.p, S, n * D));
   ND4_TRY(nd4hip_dpotrf_batched_dev(h, batch, N, (const double*)dS.p, (double*)dL.p));
   ND4_TRY(d2h(h, L, dL.p, n * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
                                          const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dpotrs_batched: negative extent");
   ND4_CHECK_ARG((strideL == 0 || strideL >= N * N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dpotrs_batched: a stride must be 0 or at least the size of one operand");
@@ -329,9 +348,9 @@ extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dpotrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* L, int64_t strideL,
                                      const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dpotrs_batched: negative extent");
   if (batch == 0 || N == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nL = (size_t)(strideL ? (batch - 1) * strideL + N * N : N * N);
   const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
   const size_t nX = (size_t)(batch * N * J);
@@ -340,13 +359,14 @@ extern "C" int nd4hip_dpotrs_batched(nd4hip_handle* h, int64_t batch, int64_t N,
   ND4_TRY(h2d(h, dL.p, L, nL * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
   ND4_TRY(nd4hip_dpotrs_batched_dev(h, batch, N, J, (const double*)dL.p, strideL, (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // ---- LDL^T: ldl_decomp (ldl.js:67-90), ldl_solve (:133-201)   
 extern "C" int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(S && LD, "nd4hip_dldltrf_batched: NULL pointer");
@@ -355,21 +375,22 @@ extern "C" int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64
 }
 extern "C" int nd4hip_dldltrf_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)(batch * N * N);
   DevBuf dS, dL;
   ND4_TRY(dS.alloc(h, n * D)); ND4_TRY(dL.alloc(h, n * D));
   ND4_TRY(h2d(h, dS.p, S, n * D));
   ND4_TRY(nd4hip_dldltrf_batched_dev(h, batch, N, (const double*)dS.p, (double*)dL.p));
   ND4_TRY(d2h(h, LD, dL.p, n * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
                                           const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dldltrs_batched: negative extent");
   ND4_CHECK_ARG((strideLD == 0 || strideLD >= N * N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dldltrs_batched: a stride must be 0 or at least the size of one operand");
@@ -381,9 +402,9 @@ extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64
 extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LD, int64_t strideLD,
                                       const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrs_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dldltrs_batched: negative extent");
   if (batch == 0 || N == 0 || J == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nL = (size_t)(strideLD ? (batch - 1) * strideLD + N * N : N * N);
   const size_t nY = (size_t)(strideY ? (batch - 1) * strideY + N * J : N * J);
   const size_t nX = (size_t)(batch * N * J);
@@ -392,13 +413,14 @@ extern "C" int nd4hip_dldltrs_batched(nd4hip_handle* h, int64_t batch, int64_t N
   ND4_TRY(h2d(h, dL.p, LD, nL * D)); ND4_TRY(h2d(h, dY.p, Y, nY * D));
   ND4_TRY(nd4hip_dldltrs_batched_dev(h, batch, N, J, (const double*)dL.p, strideLD, (const double*)dY.p, strideY, (double*)dX.p));
   ND4_TRY(d2h(h, X, dX.p, nX * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // ---- bidiag_decomp (bidiag.js:245-319)   
 extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && B && V, "nd4hip_dgebrd_batched: NULL pointer");
@@ -408,9 +430,9 @@ extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 }
 extern "C" int nd4hip_dgebrd_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const int64_t K = M < N ? M : N, J = M >= N ? K : K + 1;
   const size_t nA = (size_t)(batch * M * N), nU = (size_t)(batch * M * K), nB = (size_t)(batch * K * J), nV = (size_t)(batch * J * N);
   DevBuf dA, dU, dB, dV;
@@ -418,13 +440,14 @@ extern "C" int nd4hip_dgebrd_batched(nd4hip_handle* h, int64_t batch, int64_t M,
   ND4_TRY(h2d(h, dA.p, A, nA * D));
   ND4_TRY(nd4hip_dgebrd_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dU.p, (double*)dB.p, (double*)dV.p));
   ND4_TRY(d2h(h, U, dU.p, nU * D)); ND4_TRY(d2h(h, B, dB.p, nB * D)); ND4_TRY(d2h(h, V, dV.p, nV * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // ---- hessenberg_decomp (hessenberg.js:89-115)   
 extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && H, "nd4hip_dgehrd_batched: NULL pointer");
@@ -433,22 +456,23 @@ extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 }
 extern "C" int nd4hip_dgehrd_batched(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)(batch * N * N);
   DevBuf dU, dH;
   ND4_TRY(dU.alloc(h, n * D)); ND4_TRY(dH.alloc(h, n * D));
   ND4_TRY(h2d(h, dH.p, A, n * D));
   ND4_TRY(nd4hip_dgehrd_batched_dev(h, batch, N, (const double*)dH.p, (double*)dU.p, (double*)dH.p));      // in place on the copy
   ND4_TRY(d2h(h, U, dU.p, n * D)); ND4_TRY(d2h(h, H, dH.p, n * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // ------------------------------------------------------------------------------------ QR
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_q_batched: NULL pointer");
@@ -458,9 +482,9 @@ extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int6
 }
 extern "C" int nd4hip_dgeqrf_q_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const int64_t L = M < N ? M : N;
   const size_t nA = (size_t)(batch * M * N), nQ = (size_t)(batch * M * L), nR = (size_t)(batch * L * N);
   DevBuf dA, dQ, dR;
@@ -468,13 +492,14 @@ extern "C" int nd4hip_dgeqrf_q_batched(nd4hip_handle* h, int64_t batch, int64_t 
   ND4_TRY(h2d(h, dA.p, A, nA * D));
   ND4_TRY(nd4hip_dgeqrf_q_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dQ.p, (double*)dR.p));
   ND4_TRY(d2h(h, Q, dQ.p, nQ * D)); ND4_TRY(d2h(h, R, dR.p, nR * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // qr_decomp_full (qr.js:27-77) for every shape: Q [M, M], R [M, N]
 extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_full_batched: NULL pointer");
@@ -483,22 +508,23 @@ extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, i
 }
 extern "C" int nd4hip_dgeqrf_full_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nA = (size_t)(batch * M * N), nQ = (size_t)(batch * M * M);
   DevBuf dA, dQ, dR;
   ND4_TRY(dA.alloc(h, nA * D)); ND4_TRY(dQ.alloc(h, nQ * D)); ND4_TRY(dR.alloc(h, nA * D));
   ND4_TRY(h2d(h, dA.p, A, nA * D));
   ND4_TRY(nd4hip_dgeqrf_full_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dQ.p, (double*)dR.p));
   ND4_TRY(d2h(h, Q, dQ.p, nQ * D)); ND4_TRY(d2h(h, R, dR.p, nA * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
 // _qr_decomp_inplace (qr.js:146-183): A [M, N] <- R, Y [M, L] <- Q^T Y with the full (M x M) Q
 extern "C" int nd4hip_dgeqrf_qty_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_qty_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && L >= 0, "nd4hip_dgeqrf_qty_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && (Y || L == 0), "nd4hip_dgeqrf_qty_batched: NULL pointer");
@@ -518,9 +544,9 @@ extern "C" int nd4hip_dgeqrf_qty_batched_dev(nd4hip_handle* h, int64_t batch, in
 }
 extern "C" int nd4hip_dgeqrf_qty_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_qty_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && L >= 0, "nd4hip_dgeqrf_qty_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
-  ND4_HIP(hipSetDevice(h->device));
   const size_t nA = (size_t)(batch * M * N), nY = (size_t)(batch * M * L);
   DevBuf dA, dY;
   ND4_TRY(dA.alloc(h, nA * D)); ND4_TRY(dY.alloc(h, nY * D));
@@ -529,7 +555,7 @@ extern "C" int nd4hip_dgeqrf_qty_batched(nd4hip_handle* h, int64_t batch, int64_
   ND4_TRY(nd4hip_dgeqrf_qty_batched_dev(h, batch, M, N, L, (double*)dA.p, (double*)dY.p));
   ND4_TRY(d2h(h, A, dA.p, nA * D));
   if (nY) ND4_TRY(d2h(h, Y, dY.p, nY * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }
 
@@ -537,6 +563,7 @@ extern "C" int nd4hip_dgeqrf_qty_batched(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                           double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgesvdj_batched: negative extent");
   if (sweeps_out) *sweeps_out = 0;
   if (offnorm_out) *offnorm_out = 0.0;
@@ -559,9 +586,9 @@ extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64
 extern "C" int nd4hip_dgesvdj_batched(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                       double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_batched: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgesvdj_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) { if (sweeps_out) *sweeps_out = 0; if (offnorm_out) *offnorm_out = 0; return 0; }
-  ND4_HIP(hipSetDevice(h->device));
   const int64_t L = M < N ? M : N;
   const size_t nA = (size_t)(batch * M * N), nU = (size_t)(batch * M * L), nS = (size_t)(batch * L), nV = (size_t)(batch * L * N);
   DevBuf dA, dU, dS, dV;
@@ -570,6 +597,6 @@ extern "C" int nd4hip_dgesvdj_batched(nd4hip_handle* h, int64_t batch, int64_t M
   ND4_TRY(nd4hip_dgesvdj_batched_dev(h, batch, M, N, (const double*)dA.p, (double*)dU.p, (double*)dS.p, (double*)dV.p,
                                      sweeps_out, offnorm_out));
   ND4_TRY(d2h(h, U, dU.p, nU * D)); ND4_TRY(d2h(h, sv, dS.p, nS * D)); ND4_TRY(d2h(h, V, dV.p, nV * D));
-  ND4_HIP(hipStreamSynchronize(h->stream));
+  ND4_TRY(host_sync(h));
   return 0;
 }

@@ -39,6 +39,7 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
   hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
   if (e != hipSuccess) { nd4hip_destroy(h); return nd4_hip_fail(e, "stream/event create", __FILE__, __LINE__); }
   h->stream = h->own_stream;
   *out = h;
@@ -54,22 +55,31 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
 extern "C" int nd4hip_set_stream(nd4hip_handle* h, void* s) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_set_stream: NULL handle");
-  h->stream = reinterpret_cast<hipStream_t>(s);     // NULL = HIP's default stream
+  hipStream_t next = reinterpret_cast<hipStream_t>(s);     // NULL = HIP's default stream
+  if (next != h->stream) {
+    // the workspace arena (and cached staging) is reused in stream order: work queued on the new stream must not start
+    // before what the old stream still has in flight on those blocks
+    Nd4DeviceGuard guard(h);
+    ND4_HIP(hipEventRecord(h->ev_order, h->stream));
+    ND4_HIP(hipStreamWaitEvent(next, h->ev_order, 0));
+    h->stream = next;
+  }
   return 0;
 }
 extern "C" int nd4hip_reset_stream(nd4hip_handle* h) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_reset_stream: NULL handle");
-  h->stream = h->own_stream;
-  return 0;
+  return nd4hip_set_stream(h, h->own_stream);
 }
 extern "C" int nd4hip_synchronize(nd4hip_handle* h) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_synchronize: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -90,6 +100,7 @@ int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out) {
     ND4_HIP(hipStreamSynchronize(h->stream));
     for (auto& b : h->ws) (void)hipFree(b.p);
     h->ws.clear();
+    h->ws_generation++;
   }
   size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
   void* p = nullptr;
@@ -100,9 +111,12 @@ int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out) {
   *out = p;
   return 0;
 }
-Nd4WsScope::Nd4WsScope(nd4hip_handle* hh) : h(hh), nblocks(hh->ws.size()), used_last(hh->ws.empty() ? 0 : hh->ws.back().used) {}
+Nd4WsScope::Nd4WsScope(nd4hip_handle* hh)
+    : h(hh), nblocks(hh->ws.size()), used_last(hh->ws.empty() ? 0 : hh->ws.back().used), generation(hh->ws_generation) {}
 Nd4WsScope::~Nd4WsScope() {
-  if (h->ws.size() < nblocks) {            // the idle arena was rebuilt inside this (top-level) scope
+  if (h->ws_generation != generation) {
+    // the arena was dropped and rebuilt inside this scope: that only happens while NOTHING is in use, so this scope (and any
+    // enclosing one) held no allocation at that point and everything allocated since belongs to it -> all blocks are free again
     for (auto& b : h->ws) b.used = 0;
     return;
   }
@@ -124,23 +138,26 @@ int nd4_pinned(nd4hip_handle* h, size_t bytes, void** out) {
 
 extern "C" int nd4hip_malloc(nd4hip_handle* h, size_t bytes, void** p) {
   ND4_CHECK_ARG(h && p, "nd4hip_malloc: NULL argument");
-  ND4_HIP(hipSetDevice(h->device));
+  Nd4DeviceGuard guard(h);
   ND4_HIP(hipMalloc(p, bytes ? bytes : 8));
   return 0;
 }
 extern "C" int nd4hip_free(nd4hip_handle* h, void* p) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_free: NULL handle");
+  Nd4DeviceGuard guard(h);
   if (p) { ND4_HIP(hipStreamSynchronize(h->stream)); ND4_HIP(hipFree(p)); }
   return 0;
 }
 extern "C" int nd4hip_memcpy_h2d(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_memcpy_h2d: NULL handle");
+  Nd4DeviceGuard guard(h);
   if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
   ND4_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
 extern "C" int nd4hip_memcpy_d2h(nd4hip_handle* h, void* d, const void* s, size_t bytes) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_memcpy_d2h: NULL handle");
+  Nd4DeviceGuard guard(h);
   if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
   ND4_HIP(hipStreamSynchronize(h->stream));
   return 0;
@@ -148,11 +165,13 @@ extern "C" int nd4hip_memcpy_d2h(nd4hip_handle* h, void* d, const void* s, size_
 
 extern "C" int nd4hip_timer_start(nd4hip_handle* h) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_timer_start: NULL handle");
+  Nd4DeviceGuard guard(h);
   ND4_HIP(hipEventRecord(h->ev0, h->stream));
   return 0;
 }
 extern "C" int nd4hip_timer_stop(nd4hip_handle* h, float* ms) {
   ND4_CHECK_ARG(h && ms, "nd4hip_timer_stop: NULL argument");
+  Nd4DeviceGuard guard(h);
   ND4_HIP(hipEventRecord(h->ev1, h->stream));
   ND4_HIP(hipEventSynchronize(h->ev1));
   ND4_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -175,6 +194,7 @@ __global__ void fill_uniform_kernel(uint32_t seed, uint32_t offset, int64_t n, d
 }
 extern "C" int nd4hip_fill_uniform_dev(nd4hip_handle* h, uint32_t seed, uint32_t offset, int64_t n, double* out) {
   ND4_CHECK_ARG(h && (out || n == 0) && n >= 0, "nd4hip_fill_uniform_dev: bad argument");
+  Nd4DeviceGuard guard(h);
   if (n == 0) return 0;
   int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, seed, offset, n, out);

@@ -21,7 +21,23 @@ struct nd4hip_handle {
   void* pinned = nullptr;             // small pinned host buffer for scalar read-backs
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_order = nullptr;      // orders the workspace arena across a change of stream (nd4hip_set_stream)
   int num_cu = 256;
+  unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)
+  bool host_io_pending = false;       // async H2D/D2H of a host-pointer call in flight (staging must not be reused before a sync)
+};
+
+// Makes h->device the calling thread's current HIP device for the duration of an entry point and restores the previous
+// one: workspace hipMalloc, kernel launches and event records all act on the current device, and a caller such as torch may
+// have another device current (tensor on cuda:1 while cuda:0 is current).
+struct Nd4DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit Nd4DeviceGuard(const nd4hip_handle* h) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+  }
+  ~Nd4DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  Nd4DeviceGuard(const Nd4DeviceGuard&) = delete;
+  Nd4DeviceGuard& operator=(const Nd4DeviceGuard&) = delete;
 };
 
 void nd4_set_error(const char* fmt, ...);
@@ -39,7 +55,7 @@ int  nd4_hip_fail(hipError_t e, const char* what, const char* file, int line);
 // Nd4WsScope; allocations never move or free blocks that are in use.
 int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out);      // 256-byte aligned
 struct Nd4WsScope {
-  nd4hip_handle* h; size_t nblocks; size_t used_last;
+  nd4hip_handle* h; size_t nblocks; size_t used_last; unsigned generation;
   explicit Nd4WsScope(nd4hip_handle* hh);
   ~Nd4WsScope();
 };

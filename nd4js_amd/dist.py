@@ -10,6 +10,10 @@ Single matrices do not shard ("replicas only").
 import torch
 
 
+class PeerFailed(RuntimeError):
+    """Raised on the healthy ranks when some other rank's local work failed (all ranks leave the collective sequence together)."""
+
+
 def shard(batch, world, rank):
     """[lo, hi) of the batch axis owned by `rank`: contiguous blocks, remainder to the low ranks."""
     per, rem = divmod(int(batch), int(world))
@@ -33,20 +37,23 @@ def svd_decomp_sharded(A_local, batch_total, group=None, compute=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard(batch_total, world, rank)
     assert A_local.shape[0] == hi - lo, "A_local must be this rank's contiguous block of the batch"
-    info, failed = {}, 0.0
+    info, error = {}, None
     try:
         U, sv, V = compute(A_local, info=info)
-    except Exception:
-        failed = 1.0
-        raise
-    finally:
-        # RCCL moves device tensors directly; any other backend (gloo: CPU tests, single-GPU rehearsal) is staged
-        # through host memory
-        cdev = A_local.device if (world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
-        health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0), failed],
-                              dtype=torch.float64, device=cdev)
-        if world > 1:
-            dist.all_reduce(health, op=dist.ReduceOp.MAX, group=group)               # R1
+    except Exception as e:          # joins R1 first: the other ranks must learn of the failure before anyone enters R2
+        error = e
+    # RCCL moves device tensors directly; any other backend (gloo: CPU tests, single-GPU rehearsal) is staged
+    # through host memory
+    cdev = A_local.device if (world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
+    health = torch.tensor([float(info.get("sweeps", 0)), float(info.get("offnorm") or 0.0), 0.0 if error is None else 1.0],
+                          dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(health, op=dist.ReduceOp.MAX, group=group)               # R1
+    if error is not None:
+        raise error
+    if health[2].item() != 0.0:
+        # a peer failed (e.g. ND4HIP_ERR_NOCONV, out of memory): it never joins R2, so nobody may enter it
+        raise PeerFailed("svd_decomp_sharded: another rank failed in its local decomposition; results of rank %d discarded" % rank)
     if world > 1:
         # equal-size exchange (blocks differ by at most one matrix): pad to the largest block, gather
         # into one flat buffer (one collective, fully-connected over xGMI), trim the padding

@@ -59,3 +59,41 @@ def test_sharded_svd_world2_gloo(tmp_path):
     assert np.array_equal(sv0, sv1)               # every rank holds the whole gathered result
     ref = np.stack([oracle.svd_jac_2sided(rng.matrix(1000 + b, n, n))[1] for b in range(batch)])
     assert np.array_equal(sv0, ref)               # sharding changed nothing: bit-identical to the serial run
+
+
+def _failing_worker(rank, world, port, batch, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nd4js_amd.dist import PeerFailed
+
+    def compute(A, info=None):
+        if rank == 1:
+            raise RuntimeError("nd4hip error -4: no convergence")      # what ND4HIP_ERR_NOCONV looks like on the host
+        return _cpu_compute(A, info)
+    try:
+        lo, hi = shard(batch, world, rank)
+        A = torch.from_numpy(np.stack([rng.matrix(1000 + b, n, n) for b in range(lo, hi)]))
+        try:
+            svd_decomp_sharded(A, batch, compute=compute)
+            outcome = "returned"
+        except PeerFailed:
+            outcome = "peer_failed"
+        except RuntimeError as e:
+            outcome = "own:" + str(e)
+        dist.barrier()                          # both ranks are still in step: nobody is stuck in the all-gather
+        with open(os.path.join(out_dir, "outcome%d.txt" % rank), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_all_ranks(tmp_path):
+    """a rank whose local decomposition raises must not leave the healthy ranks blocked in R2."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_failing_worker, args=(2, port, 4, 8, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "outcome0.txt").read_text() == "peer_failed"
+    assert (tmp_path / "outcome1.txt").read_text().startswith("own:nd4hip error -4")

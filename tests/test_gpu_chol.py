@@ -192,3 +192,36 @@ def test_cholesky_exact_zero_pivot_like_reference(la):
     s = np.array([[1.0, 1.0], [1.0, 1.0]])
     L = la.cholesky_decomp(s)
     assert np.array_equal(L, oracle.cholesky_decomp(s)) and np.array_equal(L, [[1.0, 0.0], [1.0, 0.0]])
+
+
+@pytest.mark.parametrize("pos", [0, 5, 31, 32, 39])
+def test_cholesky_zero_pivot_positions_like_reference(la, pos):
+    """sqrt(0) = 0 on the diagonal, then x / 0 = +-Inf or NaN below it (cholesky.js:40): a later diagonal becomes NaN and
+    the reference throws; only a zero pivot in the LAST position returns. Positions on both sides of the 32-column block
+    boundary; the expectation is whatever the oracle (bit-exact restatement) does."""
+    N = 40
+    b = rng.matrix(5400, N, N)
+    b[pos, :] = 0.0                                   # row pos of B zero -> S[pos, :] = S[:, pos] = 0 exactly, zero pivot at pos
+    s = b @ b.T + np.diag(np.where(np.arange(N) == pos, 0.0, float(N)))
+    if pos < N - 1:
+        with pytest.raises(ValueError, match="near\\) singular"):
+            oracle.cholesky_decomp(s)
+        with pytest.raises(ValueError, match="near\\) singular"):
+            la.cholesky_decomp(s)
+    else:
+        want, got = oracle.cholesky_decomp(s), la.cholesky_decomp(s)
+        assert got[pos, pos] == 0.0 and np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_cholesky_infinite_leading_diagonal_like_reference(la):
+    """sqrt(Inf) = Inf, finite / Inf = 0 below it: the reference returns (no NaN); so must the rsqrt formulation. (An Inf
+    further down makes the reference's Kahan compensation Inf - Inf = NaN and it throws; not a contract worth mirroring.)"""
+    N = 40
+    s = rng.matrix(5500, N, N)
+    s = s @ s.T + N * np.eye(N)
+    s[0, 0] = np.inf
+    want = oracle.cholesky_decomp(s)
+    got = la.cholesky_decomp(s)
+    assert np.isinf(got[0, 0]) and not np.isnan(got).any() and np.array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    assert np.abs(got[fin] - want[fin]).max() <= 1e-12 * np.abs(want[fin]).max()
