@@ -308,6 +308,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       if (h_active[0] == 0) { last_off = *h_off; break; }
       last_off = *h_off;
       if (sweeps >= MAX_SWEEPS) break;
+      if (getenv("ND4HIP_SVD_MAXSWEEPS") && sweeps >= atoi(getenv("ND4HIP_SVD_MAXSWEEPS"))) break;    // timing experiments only
     }
   }
   if (padded) {

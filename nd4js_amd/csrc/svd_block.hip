@@ -55,21 +55,46 @@ __device__ __forceinline__ long pair_row(int x, int I, int J) { return x < BB ? 
 
 // acc (16 tiles of the 64x64 Gram of the block pair) over the columns [col0, col0 + ncols) of W, for one wave.
 // The A and B fragments of a Gram product are the same register image; one 16-byte load feeds two MFMA k-steps.
-__device__ __forceinline__ void gram_accumulate(d4 (&acc)[4][4], const double* const (&rp)[4], int col0, int ncols, int N, int fk) {
-#pragma unroll 8
-  for (int k8 = 0; k8 < ncols / 8; k8++) {
-    const int c = col0 + k8 * 8 + 2 * fk;
-    d2 f[4];
+// The order in which the columns are summed is free (A and B fragment are the same registers), so lane (fx, fk) takes the
+// 4 consecutive columns 4 fk .. 4 fk + 3 of every group of 16: the four lanes of a row then cover one whole 128-byte line with
+// their two 16-byte loads.
+__device__ __forceinline__ void gram_load_group(d2 (&dst)[2][4], const double* const (&rp)[4], int c) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) f[t] = (c < N) ? *reinterpret_cast<const d2*>(rp[t] + c) : d2{0.0, 0.0};
-    // the Gram matrix is symmetric: only the 10 tiles with j >= i are computed (mirrored in gram_reduce_lds)
+  for (int t = 0; t < 4; t++) {
+    dst[0][t] = *reinterpret_cast<const d2*>(rp[t] + c);
+    dst[1][t] = *reinterpret_cast<const d2*>(rp[t] + c + 2);
+  }
+}
+__device__ __forceinline__ void gram_mfma_group(d4 (&acc)[4][4], const d2 (&f)[2][4]) {
+  // the Gram matrix is symmetric: only the 10 tiles with j >= i are computed (mirrored in gram_reduce_lds)
+#pragma unroll
+  for (int u = 0; u < 2; u++)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = i; j < 4; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].x, f[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[i].y, f[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][i].x, f[u][j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][i].y, f[u][j].y, acc[i][j], 0, 0, 0);
       }
+}
+// NG groups of 16 columns starting at col0, all inside the matrix; the loads of group g+1 are in flight while the 40 MFMAs of
+// group g run (straight-line code: the register indices of the two fragment buffers are static)
+template <int NG>
+__device__ __forceinline__ void gram_accumulate_fixed(d4 (&acc)[4][4], const double* const (&rp)[4], int col0, int fk) {
+  d2 f[2][2][4];
+  gram_load_group(f[0], rp, col0 + 4 * fk);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    if (g + 1 < NG) gram_load_group(f[(g + 1) & 1], rp, col0 + (g + 1) * 16 + 4 * fk);
+    gram_mfma_group(acc, f[g & 1]);
+  }
+}
+// any number of columns (a multiple of 16), clipped at N (a multiple of 16)
+__device__ __forceinline__ void gram_accumulate(d4 (&acc)[4][4], const double* const (&rp)[4], int col0, int ncols, int N, int fk) {
+  for (int c0 = col0; c0 < col0 + ncols && c0 < N; c0 += 16) {
+    d2 f[2][4];
+    gram_load_group(f, rp, c0 + 4 * fk);
+    gram_mfma_group(acc, f);
   }
 }
 // fixed-order (deterministic) reduction of the four waves' tiles into an LDS image G[64][ldg]
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   nd4_rr_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const double* W = Wm + mat * sM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fx = lane & 15, fk = lane >> 4;
   const double* rp[4];
 #pragma unroll
@@ -116,7 +141,8 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  gram_accumulate(acc, rp, chunk * CH + wave * (CH / 4), CH / 4, N, fk);
+  const int col0 = chunk * CH + wave * (CH / 4);
+  if (col0 + CH / 4 <= N) gram_accumulate_fixed<CH / 64>(acc, rp, col0, fk);   // N % 64 == 0: a wave's strip is inside or outside
   gram_reduce_lds<PB + 1>(s_g, acc, wave, fk, fx);
   double* G = Gpart + mat * sG_mat + ((long)pairIdx * nchunks + chunk) * (PB * PB);
   for (int e = threadIdx.x; e < PB * PB; e += 256) G[e] = s_g[e / PB][e % PB];
@@ -150,7 +176,7 @@ __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpa
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-    const int per = ((N + 31) / 32) * 8;                      // columns per wave, multiple of 8
+    const int per = ((N + 63) / 64) * 16;                     // columns per wave, multiple of 16
     gram_accumulate(acc, rp, wave * per, per, N, fk);
     gram_reduce_lds<PB + 1>(G, acc, wave, fk, fx);
     for (int e = t; e < PB * PB; e += 256) Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
@@ -374,6 +400,384 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen8(const double* __restric
   }
 }
 
+// ---- cross-only rotation rounds with ONE barrier per round ------------------------------------------------------------
+// The 32 rounds of a cross-only visit are a dependent chain (the angles of round r+1 need the Gram matrix after round r),
+// so the visit costs 32 x the latency of one round. jacb_eigen(8) spends ~3600 cycles per round: a row phase and a column
+// phase through LDS with a barrier after each, every wave recomputing angles it then broadcasts. Here a round is
+//   read pivots + operands (all LDS reads of the round issued up front) -> angle -> rotate 2x2 blocks in registers ->
+//   write -> barrier
+// built on three observations:
+//  * With ALL 32 angles of a round known, G' = R G R^T can be formed block-wise: the 2x2 block (row pair i, column pair j)
+//    of G' depends only on the same block of G and on the angles of i and j. No separate row and column phase.
+//  * Thread (row pair i, column pairs j) always owns the same entries of the A quadrant (rows and columns of block I keep their
+//    place): they stay in registers. C = G[I][J] and B = G[J][J] are double-buffered in LDS (read buffer r&1, write the other), so
+//    the reads and writes of a round need no barrier between them. The C^T quadrant is never stored (symmetry).
+//  * The accumulated transform Q only consumes angles: its update for round r is issued in round r+1, inside the latency of that
+//    round's angle chain. Rows of Q that belong to block I stay in registers, rows of block J pass through LDS.
+// Every wave computes all 32 angles itself (lane l: pair l & 31): 4 waves = 4 SIMDs, nothing is broadcast through LDS except the
+// column-pair angles (ds_bpermute). Angle formulas: c^2 = (1 + |d|/root)/2, s = g/(root*c), t = s/c, tau = s/(1+c) with
+// d = b - a, root = sqrt(d^2 + 4 g^2): two rsqrt chains and one rcp chain, no IEEE division.
+template <int NWV>                        // waves per workgroup: 4 or 8 (2 per SIMD: a lone wave only issues every other slot)
+__global__ __launch_bounds__(64 * NWV) void jacb_eigen_x(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                                     JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                                     double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                                     unsigned long long* __restrict__ offmax, int max_inner, int dbg) {
+  constexpr int T = 64 * NWV, NB = 16 / NWV, NQ = 32 / NWV, KL = (PB * PB / 2) / T;
+  constexpr int LD = BB + 1;
+  __shared__ double sC[2][BB][LD];        // C(x, y) = G[x][32 + y]
+  __shared__ double sB[2][BB][LD];        // B(x, y) = G[32 + x][32 + y] (both triangles)
+  __shared__ double sD[2][BB];            // diagonal of the A quadrant
+  __shared__ double stage[PB][PB + 1];    // the summed Gram matrix on entry; afterwards its first 32 rows hold QJ (rows of Q of block J)
+  __shared__ double sRd[PB];              // 1 / diagonal (pre-check)
+  double (*QJ)[PB + 1] = stage;
+  const int pairIdx = blockIdx.x, mat = blockIdx.y;
+  if (st[mat].done) return;
+  int I, J;
+  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  if (J >= nblk) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  {
+    // sum of the column chunks' partial Gram matrices, chunk order fixed; 16-byte loads, all of a chunk group in flight at once
+    const d2* Gp = reinterpret_cast<const d2*>(Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB));
+    d2 acc[KL];
+#pragma unroll
+    for (int k = 0; k < KL; k++) acc[k] = d2{0.0, 0.0};
+    for (int ch0 = 0; ch0 < nchunks; ch0 += 4) {
+      d2 v[4][KL];
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int k = 0; k < KL; k++)
+          v[c][k] = (ch0 + c < nchunks) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + T * k] : d2{0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int k = 0; k < KL; k++) acc[k] += v[c][k];
+    }
+#pragma unroll
+    for (int k = 0; k < KL; k++) {
+      const int e = 2 * (t + T * k);
+      stage[e / PB][e % PB] = acc[k].x;
+      stage[e / PB][e % PB + 1] = acc[k].y;
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) return;
+  const double fl = floor2[mat];
+  // one pass over the off-diagonal: the largest cos^2 between two rows of the pair as they are NOW (the off-norm that the
+  // driver reports is the maximum over the visits of the last sweep), and whether any pair needs a rotation at all
+  if (t < PB) { const double dd = stage[t][t]; sRd[t] = dd > fl ? __builtin_amdgcn_rcp(dd) : 0.0; }   // 0: row at the noise floor
+  __syncthreads();
+  {
+    double rel = 0.0;
+    for (int e = t; e < PB * PB; e += T) {
+      const int x = e / PB, y = e % PB;
+      const double g = stage[x][y];
+      if (x < y) rel = fmax(rel, g * g * sRd[x] * sRd[y]);           // cos^2 (to the accuracy of v_rcp_f64: used for the decision
+    }                                                                //  with a 2^-20 margin, the rounds apply the exact criterion)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off));
+    if (lane == 0 && rel > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
+    const int need = __syncthreads_or(rel > tol2 * (1.0 - 0x1p-20));
+    if (!need || dbg == 2) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
+  }
+  const int i = lane & 31, h = lane >> 5;
+  const int jb = NB * (2 * wave + h);     // this thread's column pairs jb .. jb+NB-1
+  const int cb = NQ * (2 * wave + h);     // and its NQ columns of Q
+  double Areg[NB], Qp[NQ];
+#pragma unroll
+  for (int m = 0; m < NB; m++) Areg[m] = stage[i][jb + m];
+#pragma unroll
+  for (int m = 0; m < NQ; m++) Qp[m] = (cb + m == i) ? 1.0 : 0.0;
+  for (int e = t; e < BB * BB; e += T) {
+    const int x = e / BB, y = e % BB;
+    sC[0][x][y] = stage[x][BB + y];
+    sB[0][x][y] = stage[BB + x][BB + y];
+  }
+  if (t < BB) sD[0][t] = stage[t][t];
+  __syncthreads();                        // everybody is done with `stage`
+  for (int e = t; e < BB * PB; e += T) QJ[e / PB][e % PB] = (e % PB == BB + e / PB) ? 1.0 : 0.0;
+  __syncthreads();
+
+  unsigned total = 0, rot = 0;
+  double ps = 0.0, ptau = 0.0;            // angle of the previous round (pending update of Q)
+  int pip = 0;
+  const int nrounds = dbg == 3 ? 0 : BB * (max_inner < 1 ? 1 : max_inner);
+  for (int r = 0; r < nrounds; r++) {
+    const int cur = r & 1, nxt = cur ^ 1;
+    const int ip = (i + r) & (BB - 1);    // row pair i = rows (i, 32 + ip)
+    // ---- every LDS read of the round ----
+    const double a = sD[cur][i], b = sB[cur][ip][ip], g = sC[cur][i][ip];
+    double xpq[NB], xqp[NB], xqq[NB];
+    int jp[NB];
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      jp[m] = (jb + m + r) & (BB - 1);
+      xpq[m] = sC[cur][i][jp[m]];
+      xqp[m] = sC[cur][jb + m][ip];
+      xqq[m] = sB[cur][ip][jp[m]];
+    }
+    double uq[NQ];
+#pragma unroll
+    for (int m = 0; m < NQ; m++) uq[m] = QJ[pip][cb + m];
+    // ---- angle of pair i (the same in every wave) ----
+    const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
+    const double d = b - a, hh = g + g, rr = fma(d, d, hh * hh);
+    const double rs = fast_rsqrt(rr);                       // 1 / root
+    const double x = fma(0.5 * fabs(d), rs, 0.5);           // c^2 in [1/2, 1]
+    const double ric = fast_rsqrt(x);                       // 1 / c
+    const double c = x * ric;
+    const double sabs = fabs(g) * rs * ric;                 // |s| = |g| / (root c)
+    double s = ((d < 0.0) != (g < 0.0)) ? -sabs : sabs;
+    double tau = s * fast_rcp(1.0 + c);
+    if (!go) { s = 0.0; tau = 0.0; }
+    rot += (unsigned)__popc((unsigned)__ballot(go));        // lanes 0..31 = the 32 pairs of the round
+    // ---- pending update of Q (round r-1): only needs the old angle, fills the latency of the chain above ----
+#pragma unroll
+    for (int m = 0; m < NQ; m++) {
+      const double up = Qp[m];
+      Qp[m] = up - ps * (uq[m] + ptau * up);
+      QJ[pip][cb + m] = uq[m] + ps * (up - ptau * uq[m]);
+    }
+    ps = s; ptau = tau; pip = ip;
+    // ---- the 2x2 blocks (row pair i, column pair jb+m): left rotation with (s, tau), right with the column pair's.
+    // The pivot block (jb+m == i) goes through the same formulas: its off-diagonal comes out as the rounding residual of the
+    // annihilation (not an exact 0), which keeps G consistent with the accumulated Q. ----
+    double sjv[NB], tjv[NB];
+#pragma unroll
+    for (int m = 0; m < NB; m++) { sjv[m] = __shfl(s, jb + m); tjv[m] = __shfl(tau, jb + m); }
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      const double sj = sjv[m], tj = tjv[m];
+      const double xpp = Areg[m];
+      const double ypp = xpp - s * (xqp[m] + tau * xpp), yqp = xqp[m] + s * (xpp - tau * xqp[m]);
+      const double ypq = xpq[m] - s * (xqq[m] + tau * xpq[m]), yqq = xqq[m] + s * (xpq[m] - tau * xqq[m]);
+      const double zpp = ypp - sj * (ypq + tj * ypp);
+      const double zpq = ypq + sj * (ypp - tj * ypq);
+      const double zqq = yqq + sj * (yqp - tj * yqq);
+      Areg[m] = zpp;
+      if (jb + m == i) sD[nxt][i] = zpp;
+      sC[nxt][i][jp[m]] = zpq;
+      sB[nxt][ip][jp[m]] = zqq;
+    }
+    __syncthreads();
+    if ((r & (BB - 1)) == BB - 1) {                         // end of an inner sweep (uniform: every wave counts all 32 pairs)
+      total += rot;
+      if (rot == 0) break;
+      rot = 0;
+    }
+  }
+  // the update of Q that is still pending
+#pragma unroll
+  for (int m = 0; m < NQ; m++) {
+    const double uqm = QJ[pip][cb + m], up = Qp[m];
+    Qp[m] = up - ps * (uqm + ptau * up);
+    QJ[pip][cb + m] = uqm + ps * (up - ptau * uqm);
+  }
+  __syncthreads();
+  if (total) {
+    double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
+#pragma unroll
+    for (int m = 0; m < NQ; m++) Qt[i * PB + cb + m] = Qp[m];
+    for (int e = t; e < BB * PB; e += T) Qt[BB * PB + e] = QJ[e / PB][e % PB];
+  }
+  if (t == 0) {
+    flags[mat * sF_mat + pairIdx] = total ? 1 : 0;
+    if (total) atomicAdd(&st[mat].rotations, total);
+  }
+}
+
+// ---- the same rounds with a dedicated pivot wave -------------------------------------------------------------------------
+// Measured (tools/lat_f64.hip): one wave issues one fp64 instruction per 8 cycles whether or not it depends on the previous
+// one, so a round costs every wave of jacb_eigen_x (angle chain ~50 + its blocks) x 8 cycles, ~1800 cycles in all. Here the
+// chain runs on ONE wave while eight others rotate: in interval k (between two barriers)
+//   pivot wave : pivots of S_k from the near-diagonal entries of S_{k-1} and the angles of round k-1 (diagonal blocks in closed
+//                form, the off-diagonal pivot = one entry of block (i, i+1)), then the angle chain of round k -> LDS
+//   bulk waves : S_k = R_{k-1} S_{k-1} R_{k-1}^T and Q_k = R_{k-1} Q_{k-1}, angles of round k-1 read from LDS
+// Both read state k-1 and write state k (double-buffered), so one barrier per round remains and its critical path is
+// max(pivot, bulk) instead of their sum. The pivot wave keeps its own a, b, g in registers; they differ from the bulk's copies
+// by rounding only, and only the pivot wave's decide the angles that G and Q are BOTH rotated with, so G stays consistent
+// with the accumulated Q.
+__global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                                     JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                                     double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                                     unsigned long long* __restrict__ offmax, int dbg) {
+  constexpr int T = 576, TB = 512, NB = 2, NQ = 4;
+  constexpr int LD = BB + 1;
+  __shared__ double sC[2][BB][LD];        // C(x, y) = G[x][32 + y]
+  __shared__ double sB[2][BB][LD];        // B(x, y) = G[32 + x][32 + y] (both triangles)
+  __shared__ double sA1[2][BB];           // A(i, i+1): the one entry of the A quadrant the pivot wave needs
+  __shared__ double sAng[2][2][BB];       // [round parity][s | tau][pair]
+  __shared__ double stage[PB][PB + 1];    // the summed Gram matrix on entry; afterwards its first 32 rows hold QJ (rows of Q of block J)
+  __shared__ double sRd[PB];              // 1 / diagonal (pre-check)
+  __shared__ unsigned sTotal;
+  double (*QJ)[PB + 1] = stage;
+  const int pairIdx = blockIdx.x, mat = blockIdx.y;
+  if (st[mat].done) return;
+  int I, J;
+  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  if (J >= nblk) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < TB) {
+    // sum of the column chunks' partial Gram matrices, chunk order fixed; 16-byte loads, all of a chunk group in flight at once
+    constexpr int KL = (PB * PB / 2) / TB;
+    const d2* Gp = reinterpret_cast<const d2*>(Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB));
+    d2 acc[KL];
+#pragma unroll
+    for (int k = 0; k < KL; k++) acc[k] = d2{0.0, 0.0};
+    for (int ch0 = 0; ch0 < nchunks; ch0 += 4) {
+      d2 v[4][KL];
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int k = 0; k < KL; k++)
+          v[c][k] = (ch0 + c < nchunks) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + TB * k] : d2{0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int k = 0; k < KL; k++) acc[k] += v[c][k];
+    }
+#pragma unroll
+    for (int k = 0; k < KL; k++) {
+      const int e = 2 * (t + TB * k);
+      stage[e / PB][e % PB] = acc[k].x;
+      stage[e / PB][e % PB + 1] = acc[k].y;
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) return;
+  const double fl = floor2[mat];
+  if (t < PB) { const double dd = stage[t][t]; sRd[t] = dd > fl ? __builtin_amdgcn_rcp(dd) : 0.0; }   // 0: row at the noise floor
+  __syncthreads();
+  {
+    double rel = 0.0;
+    for (int e = t; e < PB * PB; e += T) {
+      const int x = e / PB, y = e % PB;
+      const double g = stage[x][y];
+      if (x < y) rel = fmax(rel, g * g * sRd[x] * sRd[y]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off));
+    if (lane == 0 && rel > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
+    const int need = __syncthreads_or(rel > tol2 * (1.0 - 0x1p-20));
+    if (!need || dbg == 2) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
+  }
+  const int i = lane & 31, h = lane >> 5;
+  const bool pivot = wave == 8;
+  const int jb = NB * (2 * wave + h);     // bulk: this thread's column pairs jb, jb+1
+  const int cb = NQ * (2 * wave + h);     // and its 4 columns of Q
+  double Areg[NB] = {0.0, 0.0}, Qp[NQ] = {0.0, 0.0, 0.0, 0.0};
+  double pa = 0.0, pb = 0.0, pg = 0.0;    // pivot wave: A(i,i), B(ip,ip), C(i,ip) of the current state
+  if (pivot) {
+    pa = stage[i][i]; pb = stage[BB + i][BB + i]; pg = stage[i][BB + i];
+  } else {
+#pragma unroll
+    for (int m = 0; m < NB; m++) Areg[m] = stage[i][jb + m];
+#pragma unroll
+    for (int m = 0; m < NQ; m++) Qp[m] = (cb + m == i) ? 1.0 : 0.0;
+  }
+  for (int e = t; e < BB * BB; e += T) {
+    const int x = e / BB, y = e % BB;
+    sC[0][x][y] = stage[x][BB + y];
+    sB[0][x][y] = stage[BB + x][BB + y];
+  }
+  if (t < BB) sA1[0][t] = stage[t][(t + 1) & (BB - 1)];
+  __syncthreads();                        // everybody is done with `stage`
+  for (int e = t; e < BB * PB; e += T) QJ[e / PB][e % PB] = (e % PB == BB + e / PB) ? 1.0 : 0.0;
+  if (dbg == 3) return;
+  // interval k = 0 .. 32: the pivot wave produces the angles of round k (k < 32), the bulk applies round k-1 (k > 0)
+  unsigned rot = 0;
+  double ps = 0.0, ptau = 0.0, sn = 0.0, tn = 0.0;   // pivot wave: angle of round k-1 for pair i and for pair i+1
+  for (int k = 0; k <= BB; k++) {
+    const int prv = (k + 1) & 1, cur = k & 1;                     // state k-1 lives in buffer prv, state k goes to cur
+    if (pivot) {
+      if (k > 0) {
+        // pg <- entry z_pq of block (i, i+1) of round k-1 (the neighbour's angle was fetched at the end of the last interval)
+        const int ipp = (i + k - 1) & (BB - 1), y = (i + k) & (BB - 1), i1 = (i + 1) & (BB - 1);
+        const double xpp = sA1[prv][i], xpq = sC[prv][i][y], xqp = sC[prv][i1][ipp], xqq = sB[prv][ipp][y];
+        const double ypq = xpq - ps * (xqq + ptau * xpq), ypp = xpp - ps * (xqp + ptau * xpp);
+        pg = ypq + sn * (ypp - tn * ypq);
+      }
+      if (k < BB) {
+        const double a = pa, b = pb, g = pg;
+        const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
+        const double d = b - a, hh = g + g, rr = fma(d, d, hh * hh);
+        const double rs = fast_rsqrt(rr);                       // 1 / root
+        const double x = fma(0.5 * fabs(d), rs, 0.5);           // c^2 in [1/2, 1]
+        const double ric = fast_rsqrt(x);                       // 1 / c
+        const double c = x * ric;
+        const double sabs = fabs(g) * rs * ric;                 // |s| = |g| / (root c)
+        double s = ((d < 0.0) != (g < 0.0)) ? -sabs : sabs;
+        double tau = s * fast_rcp(1.0 + c);
+        double tt = s * ric;                                    // tan(theta)
+        if (!go) { s = 0.0; tau = 0.0; tt = 0.0; }
+        rot += (unsigned)__popc((unsigned)__ballot(go));
+        ps = s; ptau = tau;
+        if (h == 0) { sAng[cur][0][i] = s; sAng[cur][1][i] = tau; }
+        // diagonal blocks in closed form: A(i,i) and B(ip,ip) after this round; the latter is the next pivot b of pair i-1,
+        // and pair i+1's angle turns the columns of block (i, i+1): neighbour exchange now, hidden behind the barrier
+        const int i1 = (i + 1) & (BB - 1);
+        pa = a - tt * g;
+        pb = __shfl(b + tt * g, i1);
+        sn = __shfl(s, i1); tn = __shfl(tau, i1);
+      }
+    } else if (k > 0) {
+      const int r = k - 1;
+      const int ip = (i + r) & (BB - 1);
+      const double s = sAng[prv][0][i], tau = sAng[prv][1][i];
+      double xpq[NB], xqp[NB], xqq[NB], sjv[NB], tjv[NB], uq[NQ];
+      int jp[NB];
+#pragma unroll
+      for (int m = 0; m < NB; m++) {
+        jp[m] = (jb + m + r) & (BB - 1);
+        xpq[m] = sC[prv][i][jp[m]];
+        xqp[m] = sC[prv][jb + m][ip];
+        xqq[m] = sB[prv][ip][jp[m]];
+        sjv[m] = sAng[prv][0][jb + m];
+        tjv[m] = sAng[prv][1][jb + m];
+      }
+#pragma unroll
+      for (int m = 0; m < NQ; m++) uq[m] = QJ[ip][cb + m];
+#pragma unroll
+      for (int m = 0; m < NB; m++) {
+        const double sj = sjv[m], tj = tjv[m];
+        const double xpp = Areg[m];
+        const double ypp = xpp - s * (xqp[m] + tau * xpp), yqp = xqp[m] + s * (xpp - tau * xqp[m]);
+        const double ypq = xpq[m] - s * (xqq[m] + tau * xpq[m]), yqq = xqq[m] + s * (xpq[m] - tau * xqq[m]);
+        const double zpp = ypp - sj * (ypq + tj * ypp);
+        const double zpq = ypq + sj * (ypp - tj * ypq);
+        const double zqq = yqq + sj * (yqp - tj * yqq);
+        Areg[m] = zpp;
+        if (jb + m == ((i + 1) & (BB - 1))) sA1[cur][i] = zpp;
+        sC[cur][i][jp[m]] = zpq;
+        sB[cur][ip][jp[m]] = zqq;
+      }
+#pragma unroll
+      for (int m = 0; m < NQ; m++) {
+        const double up = Qp[m];
+        Qp[m] = up - s * (uq[m] + tau * up);
+        QJ[ip][cb + m] = uq[m] + s * (up - tau * uq[m]);
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 8 * 64) sTotal = rot;
+  __syncthreads();
+  const unsigned total = sTotal;
+  if (total) {
+    double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
+    if (!pivot) {
+#pragma unroll
+      for (int m = 0; m < NQ; m++) Qt[i * PB + cb + m] = Qp[m];
+    }
+    for (int e = t; e < BB * PB; e += T) Qt[BB * PB + e] = QJ[e / PB][e % PB];
+  }
+  if (t == 0) {
+    flags[mat * sF_mat + pairIdx] = total ? 1 : 0;
+    if (total) atomicAdd(&st[mat].rotations, total);
+  }
+}
+
 __global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
                                                    const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
                                                    const int* __restrict__ flags, long sF_mat, int nchunks) {
@@ -446,6 +850,18 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
     } else {
       hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                          W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+      static const int xdbg = getenv("ND4HIP_JAC_XDBG") ? atoi(getenv("ND4HIP_JAC_XDBG")) : 0;   // timing experiments only
+      static const int xk = getenv("ND4HIP_JAC_XKERNEL") ? atoi(getenv("ND4HIP_JAC_XKERNEL")) : 9;
+      if (xk == 9 && cross && step > 0 && max_inner == 1) {
+        hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)npairs, (unsigned)batch), dim3(576), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, xdbg);
+      } else if (xk == 4 && cross && step > 0) {
+        hipLaunchKernelGGL(jacb_eigen_x<4>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner, xdbg);
+      } else if (xk && cross && step > 0) {
+        hipLaunchKernelGGL(jacb_eigen_x<8>, dim3((unsigned)npairs, (unsigned)batch), dim3(512), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner, xdbg);
+      } else {
       // ND4HIP_JAC_EIGEN8 = 0 (4 waves always) | 8 | 16; default: 16 waves when there are few workgroups
       static const int e8 = getenv("ND4HIP_JAC_EIGEN8") ? atoi(getenv("ND4HIP_JAC_EIGEN8")) : -1;
       const bool eight = e8 >= 0 ? e8 != 0 : ((long)batch * npairs <= 256);     // few workgroups: latency, not throughput, matters
@@ -461,6 +877,7 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
       hipLaunchKernelGGL(jacb_eigen<false>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
                          Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
                          (cross && step > 0) ? 1 : 0);
+      }
     }
     hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
                        W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks);
