@@ -33,10 +33,14 @@ def parse():
     return p.parse_args()
 
 
+# The true reference (nd4js dist/nd.js under Node 12) timed in the survey container (8-vCPU Xeon 2.1 GHz, 1 thread):
+# fixed reference points printed beside the port's numbers; the reference cannot travel to the GPU box.
+REFERENCE_JS_SURVEY_S = {"matmul4096": 126.1, "qr2048": 11.43, "lu2048": 6.26, "svd2048": 70.5, "svd512": 1.407}
+
+
 def cpu_baseline_matmul(n, rows):
     """Oracle (CPU port of matmul.js:49-53) on a bounded sample: the first `rows` rows of C, i.e.
     the same i-k-j loop streaming all of B, 1 thread (the reference is single-threaded)."""
-    import numpy as np
     import oracle
     from nd4js_amd import rng
     a = rng.matrix(5, n, n)[:rows].copy()
@@ -46,7 +50,38 @@ def cpu_baseline_matmul(n, rows):
     dt = time.perf_counter() - t
     return {"value": round(2.0 * rows * n * n / dt / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
             "sample": "rows 0..%d of the %dx%d product (oracle/nd4_oracle.c i-k-j loop, %.1f s)" % (rows - 1, n, n, dt),
-            "host_cpus": os.cpu_count()}, c
+            "host_cpus": os.cpu_count(),
+            "reference_js_survey_s": REFERENCE_JS_SURVEY_S,
+            "reference_js_survey_gflops": round(2.0 * 4096 ** 3 / REFERENCE_JS_SURVEY_S["matmul4096"] / 1e9, 3)}, c
+
+
+def cpu_baseline_ops(n=2048):
+    """The oracle (C port, 1 core, same flop conventions) beside every side op: LU and QR of the full 2048^2 config once each,
+    two-sided Jacobi SVD (svd_jac_2sided.js) at 512^2 (the 2048^2 run would take minutes)."""
+    import oracle
+    from nd4js_amd import rng
+    out = {}
+    a = rng.matrix(7, n, n)
+    t = time.perf_counter()
+    lu, p = oracle.lu_decomp(a)
+    dt = time.perf_counter() - t
+    out["lu%d" % n] = {"seconds": round(dt, 3), "gflops": round(2.0 / 3.0 * n ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
+                       "reference_js_survey_s": REFERENCE_JS_SURVEY_S.get("lu%d" % n)}
+    t = time.perf_counter()
+    q, r = oracle.qr_decomp(a)
+    dt = time.perf_counter() - t
+    out["qr%d" % n] = {"seconds": round(dt, 3), "gflops": round(8.0 / 3.0 * n ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
+                       "reference_js_survey_s": REFERENCE_JS_SURVEY_S.get("qr%d" % n)}
+    m = 512
+    x = rng.matrix(1000, m, m)
+    t = time.perf_counter()
+    _, sv, _, sweeps = oracle.svd_jac_2sided(x)
+    dt = time.perf_counter() - t
+    out["svd%d" % m] = {"seconds": round(dt, 3), "gflops_nominal": round(21.0 * m ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
+                        "algorithm": "two-sided Jacobi (svd_jac_2sided.js:95-134), %d sweeps" % sweeps,
+                        "reference_js_survey_s": REFERENCE_JS_SURVEY_S["svd512"],
+                        "note": "sample for the 2048^2 and the 1024 x 512^2 configs: matrix 0 of the batch"}
+    return out, (p, r, sv)
 
 
 def launch_ranks(args):
@@ -120,9 +155,25 @@ def main():
     flops = 2.0 * n ** 3
     value = world * flops * args.steps / elapsed / 1e9
 
+    # side measurements on EVERY rank (svd_batch is sharded): a failure on one rank must not leave the others in a collective
+    ops, ops_error = None, None
+    if not args.no_ops:
+        import bench_ops
+        try:
+            ops = bench_ops.run(world, rank, local, dist)
+        except Exception as e:  # reported, and the run is marked invalid below
+            ops_error = repr(e)
+    failed = 1.0 if ops_error else 0.0
+    if dist is not None:
+        tt = torch.tensor([failed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        failed = tt.item()
+
     out = None
     if rank == 0:
+        import numpy as np
         achieved = flops / (kernel_ms * 1e-3) / 1e12
+        gates = {}                                        # name -> (value, limit): every one is ENFORCED below
         out = {
             "metric": "fp64 GFLOP/s: matmul N=4096 & SVD N=2048; % of MFMA/HBM peak",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -137,59 +188,81 @@ def main():
         }
         # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of this same command
         # (tools/pmc_summary.py -> profiles/; a profiler cannot wrap itself inside the timed run)
-        try:
-            pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r"))
-            for rnd in reversed(pmc):
-                f = os.path.join(ROOT, "profiles", rnd, "gemm4096_pmc.json")
-                if os.path.exists(f) and n == 4096:
-                    with open(f) as fh:
-                        out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/%s/gemm4096_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)" % rnd
-                    break
-        except Exception:  # pragma: no cover
-            pass
-        # parity gate printed with the number
-        try:
-            import numpy as np
-            with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
-                g = json.load(f)["cases"].get("c2_matmul4096")
-            if g and n == 4096:
-                idx = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", g["files"]["idx"])).astype("int64")).cuda()
-                val = np.load(os.path.join(ROOT, "tests", "golden", g["files"]["val"]))
-                got = C.reshape(-1)[idx].cpu().numpy()
-                out["parity"] = {"matmul_vs_reference_samples_relerr": float(np.linalg.norm(got - val) / np.linalg.norm(val)), "gate": 1e-10}
-        except Exception as e:  # pragma: no cover
-            out["parity"] = {"error": repr(e)}
+        pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.startswith("r")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        for rnd in reversed(pmc):
+            f = os.path.join(ROOT, "profiles", rnd, "gemm4096_pmc.json")
+            if os.path.exists(f) and n == 4096:
+                with open(f) as fh:
+                    pj = json.load(fh)
+                out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/%s/gemm4096_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)" % rnd
+                for k in ("mfma_busy_frac", "clock_ghz"):
+                    if k in pj:
+                        out["roofline"][k] = pj[k]
+                break
+        # parity gates printed with the number and enforced
+        parity = {"gate": 1e-10}
+        with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+            cases = json.load(f)["cases"]
+        g = cases.get("c2_matmul4096")
+        if g and n == 4096:
+            idx = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", g["files"]["idx"])).astype("int64")).cuda()
+            val = np.load(os.path.join(ROOT, "tests", "golden", g["files"]["val"]))
+            got = C.reshape(-1)[idx].cpu().numpy()
+            parity["matmul_vs_reference_samples_relerr"] = float(np.linalg.norm(got - val) / np.linalg.norm(val))
+            gates["matmul_vs_reference_samples_relerr"] = (parity["matmul_vs_reference_samples_relerr"], 1e-10)
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                import numpy as np
-                cb, c_cpu = cpu_baseline_matmul(n, min(2048, n))
-                out["cpu_baseline"] = cb
-                out.setdefault("parity", {})["matmul_vs_oracle_rows_relerr"] = float(
-                    np.linalg.norm(C[: c_cpu.shape[0]].cpu().numpy() - c_cpu) / np.linalg.norm(c_cpu))
-            except Exception as e:  # pragma: no cover
-                out["cpu_baseline"] = {"error": repr(e)}
-        if not args.no_ops:
-            try:
-                import bench_ops
-                out["ops"] = bench_ops.run(world, rank, local, dist)
-            except ImportError:
-                pass
-            except Exception as e:  # pragma: no cover
-                out["ops"] = {"error": repr(e)}
-    elif not args.no_ops:
-        try:
-            import bench_ops
-            bench_ops.run(world, rank, local, dist)
-        except ImportError:
-            pass
-        except Exception:
-            pass
+            cb, c_cpu = cpu_baseline_matmul(n, min(1024, n))
+            out["cpu_baseline"] = cb
+            parity["matmul_vs_oracle_rows_relerr"] = float(
+                np.linalg.norm(C[: c_cpu.shape[0]].cpu().numpy() - c_cpu) / np.linalg.norm(c_cpu))
+            gates["matmul_vs_oracle_rows_relerr"] = (parity["matmul_vs_oracle_rows_relerr"], 1e-10)
+        out["parity"] = parity
+        if ops is not None:
+            out["ops"] = ops
+            sb = ops.get("svd_batch", {})
+            if "sv_vs_reference_max_rel" in sb:
+                gates["svd_batch_sv_vs_reference_max_rel"] = (sb["sv_vs_reference_max_rel"], 1e-10)
+            if sb.get("max_offnorm") is not None:
+                gates["svd_batch_offnorm"] = (sb["max_offnorm"], sb["offnorm_gate"])
+            sv2 = ops.get("svd2048")
+            if sv2:
+                # the headline's second half as a roofline block of its own: both accountings of SURVEY.md §8(d)
+                out["roofline_svd"] = {"workload": "svd_decomp 2048x2048 fp64 (BASELINE configs[3])", "ms": sv2["ms"], "gflops_nominal_21N3": sv2["gflops_nominal"],
+                                       "sweeps": sv2["sweeps"], "rotations_applied": sv2["rotations_applied"], "offnorm": sv2["offnorm"],
+                                       "useful_jacobi": sv2["useful_jacobi"], "executed_block": sv2.get("executed_block"),
+                                       "bound": "mfma (Gram + apply) / LDS-latency chain (rotation rounds)"}
+                gates["svd2048_offnorm"] = (sv2["offnorm"], sv2["offnorm_gate"])
+            if world == 1 and not args.no_cpu_baseline:
+                # the CPU port beside every side op, and its results as one more parity check of the device results
+                cpu_ops, (p_cpu, r_cpu, sv_cpu) = cpu_baseline_ops(2048)
+                out["cpu_baseline"]["ops"] = cpu_ops
+                from nd4js_amd import dev
+                A7 = dev.fill_uniform(7, (2048, 2048))
+                LUd, Pd = dev.lu_decomp(A7)
+                parity["lu2048_P_identical_to_oracle"] = bool(np.array_equal(Pd.cpu().numpy(), p_cpu))
+                gates["lu2048_P_mismatches"] = (0.0 if parity["lu2048_P_identical_to_oracle"] else 1.0, 0.0)
+                Qd, Rd = dev.qr_decomp(A7)
+                parity["qr2048_R_vs_oracle_relerr"] = float(np.linalg.norm(Rd.cpu().numpy() - r_cpu) / np.linalg.norm(r_cpu))
+                gates["qr2048_R_vs_oracle_relerr"] = (parity["qr2048_R_vs_oracle_relerr"], 1e-10)
+                X0 = dev.fill_uniform(1000, (512, 512))
+                sv0 = dev.svd_decomp(X0)[1].cpu().numpy()
+                parity["svd512_sv_vs_oracle_max_rel"] = float(np.abs(sv0 - sv_cpu).max() / sv_cpu.max())
+                gates["svd512_sv_vs_oracle_max_rel"] = (parity["svd512_sv_vs_oracle_max_rel"], 1e-10)
+        bad = {k: v for k, (v, lim) in gates.items() if not (v <= lim)}          # NaN fails too
+        out["gates"] = {k: {"value": v, "limit": lim} for k, (v, lim) in gates.items()}
+        out["valid"] = not bad and not failed
+        if ops_error or failed:
+            out["ops_error"] = ops_error or "a side measurement failed on another rank"
+        if bad:
+            out["failed_gates"] = bad
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if not out["valid"]:
+            raise SystemExit(3)                            # a wrong result or a failed side measurement is not a benchmark
 
 
 if __name__ == "__main__":

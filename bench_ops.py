@@ -4,84 +4,108 @@
   svd_batch                   BASELINE configs[4]: batch x (512x512) SVDs, batch axis sharded over the
                               ranks (contiguous blocks), no data-path collective; afterwards a health
                               all-reduce (max sweeps / max off-norm) and the all-gather of sv over RCCL.
-Flop conventions: SURVEY.md §8(d) (LU 2/3 N^3, QR with explicit Q 8/3 N^3, SVD nominal 21 N^3).
+Timing protocol: device-resident operands, warm-ups, MEDIAN of >= 10 runs, each run bracketed by HIP events on
+the stream the kernels are launched on. Flop conventions: SURVEY.md §8(d) (LU 2/3 N^3, QR with explicit Q 8/3 N^3, SVD nominal
+21 N^3; executed Jacobi work in both accountings of that table).
 """
 import os
+import statistics
 import time
 
 import torch
 
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+EPS = 2.220446049250313e-16
 
 
-def _time(fn, h, reps):
-    fn()                                   # warm-up (workspace allocation, code load)
-    fn()                                   # and once more: after an idle phase (the CPU baseline leg) the clocks ramp up again
+def _median_ms(fn, h, reps=10, warm=2):
+    for _ in range(warm):                  # workspace allocation, code load, clocks back up after an idle phase
+        fn()
     torch.cuda.synchronize()
     h.set_stream(torch.cuda.current_stream().cuda_stream)
-    h.timer_start()
+    ms = []
     for _ in range(reps):
+        h.timer_start()
         fn()
-    return h.timer_stop() / reps
+        ms.append(h.timer_stop())
+    return statistics.median(ms), min(ms), max(ms)
+
+
+def _entry(ms3, flops, **extra):
+    ms, lo, hi = ms3
+    d = {"ms": round(ms, 3), "ms_min": round(lo, 3), "ms_max": round(hi, 3), "timing": "median of 10 (HIP events)",
+         "gflops": round(flops / ms / 1e6, 1), "frac_mfma_peak": round(flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4), "algorithmic_flops": flops}
+    d.update(extra)
+    return d
 
 
 from nd4js_amd.dist import shard  # noqa: E402  contiguous block of the batch axis owned by a rank (SURVEY.md §8e)
 
 
-def run(world, rank, local, dist, svd_batch=None, n_single=2048):
+def svd_accounting(N, ms, info, blocked=True):
+    """Both executed-work accountings of SURVEY.md §8(d) for a one-sided Jacobi SVD that took `ms`."""
+    sweeps, rot = info.get("sweeps", 0), info.get("rotations", 0)
+    f_nom = 21.0 * N ** 3
+    out = {"ms": round(ms, 2), "gflops_nominal": round(f_nom / ms / 1e6, 1), "nominal_flops": f_nom,
+           "sweeps": sweeps, "rotations_applied": rot, "rotations_per_sweep_full": N * (N - 1) // 2,
+           "offnorm": info.get("offnorm"), "offnorm_gate": N * EPS,
+           "algorithm": "block one-sided Jacobi (32-row blocks; Gram / rotation rounds / apply, Gram and apply on fp64 MFMA)" if blocked
+           else "row-pair one-sided Jacobi"}
+    # (1) §8(d) "one-sided Jacobi executed work": 7 N^2 (N-1) flop and 32 N^2 (N-1) bytes per sweep of an UNBLOCKED sweep;
+    #     counted per rotation actually applied (14 N flop, 64 N bytes each) so that skipped pairs do not inflate it
+    f_useful = 14.0 * N * rot
+    b_unblocked = 64.0 * N * rot
+    out["useful_jacobi"] = {"flops": f_useful, "tflops": round(f_useful / ms / 1e9, 3), "frac_mfma_peak": round(f_useful / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                            "unblocked_bytes": b_unblocked, "unblocked_GBps": round(b_unblocked / ms / 1e6, 1),
+                            "unblocked_frac_hbm_peak": round(b_unblocked / ms / 1e6 / PEAK_HBM_GBS, 4),
+                            "note": "14 N flop / 64 N bytes per applied rotation = SURVEY 8(d)'s 7 N^2 (N-1) flop, 32 N^2 (N-1) B per full sweep; "
+                                    "the blocked kernels keep row blocks in registers/LDS, so the byte figure can exceed the HBM peak"}
+    if blocked:
+        # (2) what the block kernels execute: per sweep 12 N^3 flop on MFMA (Gram 2/3 of 2 N^3 ... + two applies) and
+        #     5 passes over a 64-row pair per step = 40 N^2 (N/32 - 1) bytes
+        nblk = N // 32
+        f_ex = 12.0 * N ** 3 * sweeps
+        b_ex = 40.0 * N * N * (nblk - 1) * sweeps
+        out["executed_block"] = {"flops": f_ex, "tflops": round(f_ex / ms / 1e9, 2), "frac_mfma_peak": round(f_ex / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
+                                 "bytes": b_ex, "GBps": round(b_ex / ms / 1e6, 1), "frac_hbm_peak": round(b_ex / ms / 1e6 / PEAK_HBM_GBS, 4)}
+    return out
+
+
+def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True):
     from nd4js_amd import _lib, dev
     h = _lib.handle(local)
     out = {}
     if world == 1:
         N = n_single
         A = dev.fill_uniform(7, (N, N))
-        # the CPU-baseline leg before this leaves the GPU idle for ~10 s: spin the clocks back up (~0.2 s of GEMMs), otherwise
-        # the first, latency-bound measurement (LU) reads 30-40 % slow
+        # the CPU-baseline leg before this leaves the GPU idle for seconds: spin the clocks back up (~0.2 s of GEMMs)
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < 0.2:
             dev.matmul2(A, A)
             torch.cuda.synchronize()
-        ms = _time(lambda: dev.lu_decomp(A), h, 5)
-        f = 2.0 / 3.0 * N ** 3
-        out["lu%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
-                           "algorithmic_flops": f}
-        ms = _time(lambda: dev.qr_decomp(A), h, 5)
-        f = 8.0 / 3.0 * N ** 3
-        out["qr%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
-                           "algorithmic_flops": f}
+        out["lu%d" % N] = _entry(_median_ms(lambda: dev.lu_decomp(A), h), 2.0 / 3.0 * N ** 3)
+        out["qr%d" % N] = _entry(_median_ms(lambda: dev.qr_decomp(A), h), 8.0 / 3.0 * N ** 3)
         # N1 (SURVEY §8f): lu_solve with N right-hand sides on the device-resident factors: 2 N^2 J flop
         LUd, Pd = dev.lu_decomp(A)
         Y = dev.fill_uniform(11, (N, N))
-        ms = _time(lambda: dev.lu_solve(LUd, Pd, Y), h, 5)
-        f = 2.0 * N * N * N
-        out["lu_solve%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
-                                 "rhs_columns": N, "algorithmic_flops": f}
+        out["lu_solve%d" % N] = _entry(_median_ms(lambda: dev.lu_solve(LUd, Pd, Y), h), 2.0 * N ** 3, rhs_columns=N)
         # N4 (SURVEY §8f): Cholesky of S = B B^T + N I (formed on the device), N^3/3 flop
         S = dev.gemm_ex(False, True, 1.0, A, A, 0.0, torch.empty_like(A), N, N, N, N, N, N)
         S.diagonal().add_(float(N))
-        ms = _time(lambda: dev.cholesky_decomp(S), h, 5)
-        f = N ** 3 / 3.0
-        out["cholesky%d" % N] = {"ms": round(ms, 3), "gflops": round(f / ms / 1e6, 1), "frac_mfma_peak": round(f / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
-                                 "algorithmic_flops": f}
+        out["cholesky%d" % N] = _entry(_median_ms(lambda: dev.cholesky_decomp(S), h), N ** 3 / 3.0)
         A9 = dev.fill_uniform(9, (N, N))
         info = {}
-        ms = _time(lambda: dev.svd_decomp(A9, info=info), h, 1)
-        f = 21.0 * N ** 3
-        sweeps = info.get("sweeps", 0)
-        blocked = (N % 64 == 0 and N >= 128)
-        nblk = N // 32
-        if blocked:      # block Jacobi (svd_block.hip): per sweep 12 N^3 flop on MFMA, 5 passes over W/Ut per step
-            ex_flops = 12.0 * N ** 3 * sweeps
-            ex_bytes = 40.0 * N * N * (nblk - 1) * sweeps
-        else:            # row-pair Jacobi (svd.hip): SURVEY.md §8d
-            ex_flops = 7.0 * N * N * (N - 1) * sweeps
-            ex_bytes = 32.0 * N * N * (N - 1) * sweeps
-        out["svd%d" % N] = {"ms": round(ms, 2), "gflops_nominal": round(f / ms / 1e6, 1), "sweeps": sweeps,
-                            "algorithm": "block one-sided Jacobi (32-row blocks, Gram/eigen/apply on MFMA)" if blocked else "row-pair one-sided Jacobi",
-                            "executed_gflops": round(ex_flops / ms / 1e6, 1), "executed_frac_mfma_peak": round(ex_flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4),
-                            "executed_traffic_GBps": round(ex_bytes / ms / 1e6, 1), "executed_frac_hbm_peak": round(ex_bytes / ms / 1e6 / PEAK_HBM_GBS, 4),
-                            "offnorm": info.get("offnorm")}
+        ms3 = _median_ms(lambda: dev.svd_decomp(A9, info=info), h, reps=10, warm=1)
+        e = svd_accounting(N, ms3[0], info, blocked=N >= 16)
+        e.update({"ms_min": round(ms3[1], 2), "ms_max": round(ms3[2], 2), "timing": "median of 10 (HIP events)"})
+        out["svd%d" % N] = e
+        # QR panel (north_star: >= 50 % of HBM peak "on the QR panel"): geqr2 + larft of 16 columns, one workgroup per matrix;
+        # algorithmic bytes = 16 m b (each panel element read once and written once, SURVEY.md §8d)
+        try:
+            out["qr_panel"] = qr_panel(h, dev)
+        except Exception as ex:  # pragma: no cover
+            out["qr_panel"] = {"error": repr(ex)}
     # ---- batched SVD, batch axis sharded over ranks ----
     B = int(os.environ.get("ND4_BENCH_SVD_BATCH", svd_batch or 1024))
     n = 512
@@ -92,25 +116,54 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
         _lib.check(h.lib.nd4hip_fill_uniform_dev(h.ptr, 1000 + lo + k, 0, n * n, X[k].data_ptr()))
     info = {}
     dev.svd_decomp(X[: min(mine, 8)], info=info)        # warm-up on a slice
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    from nd4js_amd.dist import svd_decomp_sharded
-    U, sv_all, V, hl = svd_decomp_sharded(X, B)         # local SVDs + R1 health all-reduce + R2 sv all-gather
-    health = torch.tensor([float(hl["max_sweeps"]), hl["max_offnorm"]], dtype=torch.float64)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    nccl = dist is not None and dist.get_backend() == "nccl"
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device="cuda" if nccl else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        return tt.item()
+
+    from nd4js_amd.dist import svd_decomp_sharded
+    sync()
+    t0 = time.perf_counter()
+    U, sv_all, V, hl = svd_decomp_sharded(X, B)         # local SVDs + R1 health all-reduce + R2 sv all-gather
+    sync()
+    dt = max_over_ranks(time.perf_counter() - t0)
     f = 21.0 * n ** 3 * B
-    res = {"batch": B, "n": n, "n_gpus": world, "seconds": round(dt, 4), "gflops_nominal": round(f / dt / 1e9, 1),
-           "matrices_per_s": round(B / dt, 1), "max_sweeps": int(health[0].item()), "max_offnorm": health[1].item(),
+    res = {"batch": B, "n": n, "n_gpus": world, "matrices_per_rank": mine,
+           "kernel_only": {"seconds": round(dt, 4), "gflops_nominal": round(f / dt / 1e9, 1), "matrices_per_s": round(B / dt, 1),
+                           "what": "device-resident shard -> local SVDs -> R1 all-reduce(max) -> R2 all-gather(sv); barrier + sync on both sides, max over ranks"},
+           "seconds": round(dt, 4), "gflops_nominal": round(f / dt / 1e9, 1), "matrices_per_s": round(B / dt, 1),
+           "max_sweeps": hl["max_sweeps"], "max_offnorm": hl["max_offnorm"], "offnorm_gate": n * EPS,
            "scaling": "strong (fixed batch sharded over ranks)"}
+    if end_to_end:
+        # end-to-end through the host-pointer C ABI (what the JS host sees): this rank's block of the host batch in pinned
+        # memory -> H2D -> kernels -> D2H of U, sv, V. Expected to be PCIe-bound: 6 GiB cross the bus for 1024 matrices.
+        try:
+            import ctypes
+            hX = torch.empty((mine, n, n), dtype=torch.float64).pin_memory()
+            hX.copy_(X)
+            hU, hV = torch.empty_like(hX).pin_memory(), torch.empty_like(hX).pin_memory()
+            hS = torch.empty((mine, n), dtype=torch.float64).pin_memory()
+            sync()
+            t0 = time.perf_counter()
+            _lib.check(h.lib.nd4hip_dgesvdj_batched(h.ptr, mine, n, n, ctypes.c_void_p(hX.data_ptr()), ctypes.c_void_p(hU.data_ptr()),
+                                                    ctypes.c_void_p(hS.data_ptr()), ctypes.c_void_p(hV.data_ptr()), None, None))
+            sync()
+            de = max_over_ranks(time.perf_counter() - t0)
+            res["end_to_end"] = {"seconds": round(de, 4), "gflops_nominal": round(f / de / 1e9, 1), "matrices_per_s": round(B / de, 1),
+                                 "bytes_over_pcie_per_rank": int(mine * (3 * n * n + n) * 8), "bound": "PCIe (H2D of A, D2H of U, sv, V)",
+                                 "sv_bit_identical_to_device_resident": bool(torch.equal(hS.cuda(), sv_all[lo:hi]))}
+            del hX, hU, hV, hS
+        except Exception as ex:  # pragma: no cover
+            res["end_to_end"] = {"error": repr(ex)}
     if rank == 0:
         # parity gate: members with golden sv (every 16th) against the reference
         try:
@@ -125,7 +178,35 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048):
                 keep = members < B
                 got = sv_all[torch.from_numpy(members[keep].astype("int64")).cuda()].cpu().numpy()
                 res["sv_vs_reference_max_rel"] = float(np.abs(got - ref[keep]).max() / ref[keep].max())
+                res["members_checked"] = int(keep.sum())
         except Exception as e:  # pragma: no cover
             res["parity_error"] = repr(e)
     out["svd_batch"] = res
     return out
+
+
+def qr_panel(h, dev, M=2048, b=16, batch=256):
+    """One panel factorisation kernel (Householder geqr2 + larft of b = 16 columns) on its own: a single 2048-row panel (one
+    workgroup: a latency chain) and 256 of them in one launch (one workgroup per matrix: where an HBM fraction is meaningful)."""
+    import ctypes
+    from nd4js_amd import _lib
+    res = {"rows": M, "cols": b, "algorithmic_bytes_per_panel": 16 * M * b}
+    for name, nb in (("single", 1), ("batched", batch)):
+        A = dev.fill_uniform(21, (nb, M, b))
+        V = torch.empty_like(A)
+        T = torch.empty((nb, b, b), dtype=torch.float64, device="cuda")
+        W = A.clone()
+
+        def go():
+            W.copy_(A)
+            _lib.check(h.lib.nd4hip_dgeqr2_panel_batched_dev(h.ptr, nb, M, b, ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(V.data_ptr()),
+                                                             ctypes.c_void_p(T.data_ptr())))
+
+        def only_copy():
+            W.copy_(A)
+        ms_all = _median_ms(go, h)[0]
+        ms_copy = _median_ms(only_copy, h)[0]
+        us = max(ms_all - ms_copy, 1e-6) * 1e3
+        byts = 16.0 * M * b * nb
+        res[name] = {"panels": nb, "us": round(us, 2), "bytes": byts, "GBps": round(byts / us / 1e3, 1), "frac_hbm_peak": round(byts / us / 1e3 / PEAK_HBM_GBS, 4)}
+    return res

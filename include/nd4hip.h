@@ -195,6 +195,12 @@ int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64
 int nd4hip_dgesvdj_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
 
+/* Executed-work audit of the LAST nd4hip_dgesvdj_batched[_dev] call on this handle ("must print sweeps and
+ * rotations actually applied"; the reference's loop is svd_jac_2sided.js:95-134): sweeps = max over the batch, rotations =
+ * plane rotations applied over all matrices and sweeps, offnorm = largest |a_p.a_q| / (|a_p||a_q|) over the row pairs as they
+ * were found during the last sweep (<= N*eps at convergence). Any pointer may be NULL. */
+int nd4hip_dgesvdj_last_info(nd4hip_handle* h, int* sweeps, unsigned long long* rotations, double* offnorm);
+
 #ifdef __cplusplus
 }
 #endif

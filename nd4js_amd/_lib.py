@@ -68,6 +68,8 @@ SIGNATURES = {
                                            ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "nd4hip_dgesvdj_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
                                        ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
+    "nd4hip_dgesvdj_last_info": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_ulonglong),
+                                         ctypes.POINTER(ctypes.c_double)]),
 }
 
 
@@ -130,6 +132,12 @@ class Handle:
         ms = ctypes.c_float()
         check(self.lib.nd4hip_timer_stop(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def svd_last_info(self):
+        """sweeps, rotations applied and off-norm of the last svd_decomp on this handle (executed-work audit)"""
+        sw, rot, off = c_int(0), ctypes.c_ulonglong(0), ctypes.c_double(0.0)
+        check(self.lib.nd4hip_dgesvdj_last_info(self._h, ctypes.byref(sw), ctypes.byref(rot), ctypes.byref(off)))
+        return {"sweeps": sw.value, "rotations": rot.value, "offnorm": off.value}
 
     def close(self):
         if self._h:

@@ -49,6 +49,7 @@ static int (*p_dgebrd[2])(nd4hip_handle*, int64_t, int64_t, int64_t, const doubl
 static int (*p_dgehrd[2])(nd4hip_handle*, int64_t, int64_t, const double*, double*, double*);
 static int (*p_dgeqrf_qty[2])(nd4hip_handle*, int64_t, int64_t, int64_t, int64_t, double*, double*);
 static gesvdj_fn p_dgesvdj[2];
+static int (*p_svd_info)(nd4hip_handle*, int*, unsigned long long*, double*);
 static qrls_fn p_dqrls[2];
 static svdls_fn p_dsvdls[2];
 static getrs_fn p_dgetrs[2];
@@ -109,6 +110,7 @@ static int load_library(void) {
   SYM2(p_dsvdls, "nd4hip_dsvdls_batched");
   SYM2(p_dtrsm, "nd4hip_dtrsm_batched");
 #undef SYM2
+  SYM(p_svd_info, "nd4hip_dgesvdj_last_info");
   SYM(p_malloc, "nd4hip_malloc");
   SYM(p_free, "nd4hip_free");
   SYM(p_h2d, "nd4hip_memcpy_h2d");
@@ -315,7 +317,7 @@ static napi_value js_dgehrd(napi_env env, napi_callback_info info) {
   FAIL_IF(p_dgehrd[A.dev](g_handle, batch, N, (const double*)A.p, (double*)U.p, (double*)H.p));
   return NULL;
 }
-/* dgesvdj_batched(batch, M, N, A, U, sv, V) -> {sweeps, offnorm} */
+/* dgesvdj_batched(batch, M, N, A, U, sv, V) -> {sweeps, offnorm, rotations} */
 static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
   ARGS(7, "dgesvdj_batched");
   int64_t batch, M, N; opnd A, U, S, V;
@@ -331,6 +333,9 @@ static napi_value js_dgesvdj(napi_env env, napi_callback_info info) {
   napi_create_object(env, &r);
   napi_create_int32(env, sweeps, &v); napi_set_named_property(env, r, "sweeps", v);
   napi_create_double(env, off, &v); napi_set_named_property(env, r, "offnorm", v);
+  unsigned long long rot = 0;
+  FAIL_IF(p_svd_info(g_handle, NULL, &rot, NULL));
+  napi_create_double(env, (double)rot, &v); napi_set_named_property(env, r, "rotations", v);     /* exact up to 2^53 */
   return r;
 }
 

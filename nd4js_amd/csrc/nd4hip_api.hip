@@ -600,3 +600,11 @@ extern "C" int nd4hip_dgesvdj_batched(nd4hip_handle* h, int64_t batch, int64_t M
   ND4_TRY(host_sync(h));
   return 0;
 }
+
+extern "C" int nd4hip_dgesvdj_last_info(nd4hip_handle* h, int* sweeps, unsigned long long* rotations, double* offnorm) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_last_info: NULL handle");
+  if (sweeps) *sweeps = h->svd_sweeps;
+  if (rotations) *rotations = h->svd_rotations;
+  if (offnorm) *offnorm = h->svd_offnorm;
+  return 0;
+}

@@ -24,6 +24,7 @@ struct nd4hip_handle {
   hipEvent_t ev_order = nullptr;      // orders the workspace arena across a change of stream (nd4hip_set_stream)
   int num_cu = 256;
   unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)
+  int svd_sweeps = 0; unsigned long long svd_rotations = 0; double svd_offnorm = 0.0;   // audit of the last SVD call
   bool host_io_pending = false;       // async H2D/D2H of a host-pointer call in flight (staging must not be reused before a sync)
 };
 

@@ -98,11 +98,11 @@ __global__ __launch_bounds__(256) void jac_floor(const double* __restrict__ svr,
   if (threadIdx.x == 0) { const double m = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3])); floor2[blockIdx.x] = tol2 * m * m; }
 }
 
-__global__ void jac_sweep_end(JacState* __restrict__ st, int batch, unsigned* __restrict__ active) {
+__global__ void jac_sweep_end(JacState* __restrict__ st, int batch, unsigned* __restrict__ active, unsigned long long* __restrict__ rot_total) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= batch) return;
   if (!st[m].done) {
-    if (st[m].rotations == 0) st[m].done = 1; else atomicAdd(active, 1u);
+    if (st[m].rotations == 0) st[m].done = 1; else { atomicAdd(active, 1u); atomicAdd(rot_total, (unsigned long long)st[m].rotations); }
     st[m].rotations = 0;
   }
 }
@@ -246,7 +246,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   const size_t npad = padded ? (size_t)batch * (2 * sMp + Np) : 0;
   const size_t nd = (size_t)batch * (2 * sM + 2 * N + 1) + nblock + npad;
   const size_t nrank = ((size_t)batch * N + 1) & ~size_t(1);          // keeps the 64-bit words behind it aligned
-  ND4_TRY(nd4_ws_alloc(h, nd * sizeof(double) + nrank * sizeof(int) + (size_t)batch * sizeof(JacState) + 64, &p));
+  ND4_TRY(nd4_ws_alloc(h, nd * sizeof(double) + nrank * sizeof(int) + (size_t)batch * sizeof(JacState) + 96, &p));
   double* Ut = static_cast<double*>(p);
   double* Utp = Ut + (size_t)batch * sM;
   double* svr = Utp + (size_t)batch * sM;
@@ -260,13 +260,14 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   JacState* st = reinterpret_cast<JacState*>(rank + nrank);
   unsigned* active = reinterpret_cast<unsigned*>(st + batch);           // [1] + padding
   unsigned long long* offmax = reinterpret_cast<unsigned long long*>(active + 2);
+  unsigned long long* rot_total = offmax + 1;                           // rotations applied, summed over sweeps and matrices
   void* pin = nullptr;
   ND4_TRY(nd4_pinned(h, 64 + sizeof(int) * (size_t)batch, &pin));
   unsigned* h_active = static_cast<unsigned*>(pin);
   unsigned long long* h_off = reinterpret_cast<unsigned long long*>(h_active + 2);
 
   ND4_TRY(nd4_set_identity(h, N, N, Ut, N, batch, sM));
-  ND4_HIP(hipMemsetAsync(st, 0, sizeof(JacState) * batch + 24, h->stream));
+  ND4_HIP(hipMemsetAsync(st, 0, sizeof(JacState) * batch + 32, h->stream));
   if (padded) {
     ND4_HIP(hipMemsetAsync(Wp, 0, sizeof(double) * (size_t)batch * sMp, h->stream));
     ND4_TRY(nd4_copy_matrix(h, N, N, W, N, Wp, Np, batch, sM, sMp));
@@ -283,7 +284,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   unsigned long long last_off = 0;
   if (N > 1) {
     for (;;) {
-      ND4_HIP(hipMemsetAsync(active, 0, 24, h->stream));            // active + offmax
+      ND4_HIP(hipMemsetAsync(active, 0, 16, h->stream));            // active + offmax (the rotation total runs on)
       if (blocked) {
         ND4_TRY(nd4_jacobi_block_sweep(h, batch, Np, Wb, Utb, st, floor2, tol2, offmax, bscratch));
       } else {
@@ -291,7 +292,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
           hipLaunchKernelGGL(jac_step, dim3((unsigned)(n2 / 2), (unsigned)batch), dim3(256), 0, h->stream,
                              W, Ut, N, sM, n2, s, tol2, st, floor2, offmax);
       }
-      hipLaunchKernelGGL(jac_sweep_end, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, st, batch, active);
+      hipLaunchKernelGGL(jac_sweep_end, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, h->stream, st, batch, active, rot_total);
       ND4_HIP(hipGetLastError());
       sweeps++;
       // The convergence flag is read back (one stream synchronisation) after every sweep for large matrices; a sweep of a
@@ -299,7 +300,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       // converged matrices are skipped on the device anyway (JacState.done), an extra sweep over them rotates nothing.
       const int check_every = Np <= 64 ? 4 : (Np <= 256 ? 2 : 1);
       if (sweeps % check_every != 0 && sweeps < MAX_SWEEPS) continue;
-      ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
+      ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));   // active, offmax, rotation total
       ND4_HIP(hipStreamSynchronize(h->stream));
       if (getenv("ND4HIP_SVD_DEBUG")) {
         double r; unsigned long long bb = *h_off; memcpy(&r, &bb, 8);
@@ -351,8 +352,12 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
     }
   }
   ND4_TRY(nd4_transpose(h, N, N, Utp, N, U, N, batch, sM, sM));
-  if (sweeps_out) *sweeps_out = sweeps;
-  if (offnorm_out) { double r; unsigned long long b = last_off; memcpy(&r, &b, 8); *offnorm_out = sqrt(r); }
+  {
+    double r; unsigned long long b = last_off; memcpy(&r, &b, 8);
+    h->svd_sweeps = sweeps; h->svd_offnorm = sqrt(r); h->svd_rotations = N > 1 ? h_off[1] : 0;
+    if (sweeps_out) *sweeps_out = sweeps;
+    if (offnorm_out) *offnorm_out = h->svd_offnorm;
+  }
   if (sweeps >= MAX_SWEEPS && N > 1) {
     ND4_HIP(hipStreamSynchronize(h->stream));
     nd4_set_error("nd4hip_dgesvdj: no convergence after %d sweeps", sweeps);

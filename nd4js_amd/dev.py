@@ -113,6 +113,7 @@ def svd_decomp(A, info=None):
                                                 ctypes.byref(sweeps), ctypes.byref(off)))
     if info is not None:
         info["sweeps"], info["offnorm"] = sweeps.value, off.value
+        info["rotations"] = h.svd_last_info()["rotations"]
     return U, sv, V
 
 

@@ -220,6 +220,7 @@ def svd_decomp(A, device=None, info=None):
                                             ctypes.byref(sweeps), ctypes.byref(off)))
     if info is not None:
         info["sweeps"], info["offnorm"] = sweeps.value, off.value
+        info["rotations"] = h.svd_last_info()["rotations"]
     return U, sv, V
 
 
