@@ -38,6 +38,18 @@ int  nd4hip_device_count(void);
 /* device < 0: use the current HIP device. Creates a private non-blocking stream. */
 int  nd4hip_create(nd4hip_handle** out, int device);
 void nd4hip_destroy(nd4hip_handle* h);
+/* One handle over SEVERAL devices of the node (SURVEY.md §8b `nd4hip_init(handle**, device_ids, n_dev)`, §8e): the HOST-pointer
+ * batched entry points cut the leading batch axis — the reference's loops over independent matrices, src/la/qr.js:43-49,
+ * lu.js:34-40, svd_dc.js:918-925, matmul.js:44-70 — into contiguous blocks, one per device (nd4hip_partition), each block
+ * uploaded, computed and downloaded by its own host thread on its own device and streams; results land directly in the
+ * caller's arrays, so there is no data-path collective. The *_dev entry points, nd4hip_malloc / nd4hip_set_stream and single
+ * matrices (batch 1: "replicas only") use device_ids[0]. nd4hip_destroy releases all devices. */
+int  nd4hip_create_multi(nd4hip_handle** out, const int* device_ids, int n_dev);
+/* number of devices behind the handle; their ids are written to device_ids[0..capacity) when it is not NULL */
+int  nd4hip_device_list(nd4hip_handle* h, int* device_ids, int capacity);
+/* the block [lo, hi) of a batch that device number `index` (0-based position in the handle's list) of n_dev devices processes:
+ * contiguous, sizes differ by at most one, remainder to the low devices; devices beyond the batch get an empty block */
+int  nd4hip_partition(int64_t batch, int n_dev, int index, int64_t* lo, int64_t* hi);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). NULL is a
  * valid value: HIP's default (null) stream. nd4hip_reset_stream goes back to the private stream. */
 int  nd4hip_set_stream(nd4hip_handle* h, void* hip_stream);
@@ -194,6 +206,13 @@ int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64
                                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
 int nd4hip_dgesvdj_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A,
                                double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out);
+
+/* ---- one Householder panel on its own: geqr2 + larft of a 16-column panel (the inner step of qr_decomp, src/la/qr.js:54-68
+ * eliminates the same entries column by column with Givens rotations) ---------------------------------------------
+ * A [batch,M,16] (1 <= M <= 2048) is overwritten with R in its top 16 x 16 (entries below the diagonal are left as the kernel
+ * leaves them); V [batch,M,16] receives the explicit unit-lower reflectors, T [batch,16,16] the compact-WY factor
+ * (Q_panel = I - V T V^T). Device pointers. Exposed for the panel roofline of bench.py (16 M b bytes per panel). */
+int nd4hip_dgeqr2_panel_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t b, double* A, double* V, double* T);
 
 /* Executed-work audit of the LAST nd4hip_dgesvdj_batched[_dev] call on this handle ("must print sweeps and
  * rotations actually applied"; the reference's loop is svd_jac_2sided.js:95-134): sweeps = max over the batch, rotations =

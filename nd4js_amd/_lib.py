@@ -20,6 +20,9 @@ SIGNATURES = {
     "nd4hip_device_count": (c_int, []),
     "nd4hip_create": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int]),
     "nd4hip_destroy": (None, [ctypes.c_void_p]),
+    "nd4hip_create_multi": (c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_int), c_int]),
+    "nd4hip_device_list": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), c_int]),
+    "nd4hip_partition": (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "nd4hip_set_stream": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "nd4hip_reset_stream": (c_int, [ctypes.c_void_p]),
     "nd4hip_synchronize": (c_int, [ctypes.c_void_p]),
@@ -68,6 +71,7 @@ SIGNATURES = {
                                            ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "nd4hip_dgesvdj_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
                                        ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
+    "nd4hip_dgeqr2_panel_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
     "nd4hip_dgesvdj_last_info": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_ulonglong),
                                          ctypes.POINTER(ctypes.c_double)]),
 }
@@ -110,7 +114,16 @@ class Handle:
     def __init__(self, device=None):
         self.lib = load()
         self._h = ctypes.c_void_p()
-        check(self.lib.nd4hip_create(ctypes.byref(self._h), -1 if device is None else int(device)))
+        if isinstance(device, (list, tuple)):       # one handle over several devices: host-pointer batches are sharded
+            ids = (c_int * len(device))(*[int(d) for d in device])
+            check(self.lib.nd4hip_create_multi(ctypes.byref(self._h), ids, len(device)))
+        else:
+            check(self.lib.nd4hip_create(ctypes.byref(self._h), -1 if device is None else int(device)))
+
+    def devices(self):
+        ids = (c_int * 64)()
+        n = self.lib.nd4hip_device_list(self._h, ids, 64)
+        return [ids[i] for i in range(n)]
 
     @property
     def ptr(self):
@@ -156,7 +169,9 @@ _default = {}
 
 def handle(device=None):
     """Lazily created per-device default handle (the reference has no init step: SURVEY.md §3.5)."""
-    key = -1 if device is None else int(device)
+    if isinstance(device, Handle):
+        return device
+    key = -1 if device is None else (tuple(device) if isinstance(device, (list, tuple)) else int(device))
     with _lock:
         h = _default.get(key)
     if h is None:
@@ -164,3 +179,10 @@ def handle(device=None):
         with _lock:
             _default[key] = h
     return h
+
+
+def partition(batch, n_dev, index):
+    """[lo, hi) of the batch that device number `index` of an n_dev-device handle processes (include/nd4hip.h)"""
+    lo, hi = c_i64(0), c_i64(0)
+    check(load().nd4hip_partition(batch, n_dev, index, ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value

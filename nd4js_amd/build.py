@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libnd4hip.so")
 ADDON = os.path.join(HERE, "js", "nd4hip_napi.node")
 ARCH = "gfx950"
-HIP_SOURCES = ["nd4hip_core.hip", "nd4hip_api.hip", "gemm.hip", "lu.hip", "qr.hip", "svd.hip", "svd_block.hip", "trsm.hip", "chol.hip", "hess.hip", "bidiag.hip"]
+HIP_SOURCES = ["nd4hip_core.hip", "nd4hip_api.hip", "nd4hip_host.hip", "gemm.hip", "lu.hip", "qr.hip", "svd.hip", "svd_block.hip", "trsm.hip", "chol.hip", "hess.hip", "bidiag.hip"]
 # -pragma-unroll-threshold: the register-resident panel kernels fully unroll 16 columns x R rows x 16 FMAs;
 # below the default threshold LLVM silently keeps a rolled loop and the row arrays fall into scratch memory.
 HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-ffp-contract=on",

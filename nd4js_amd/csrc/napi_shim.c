@@ -36,6 +36,8 @@ typedef int (*getrs_fn)(nd4hip_handle*, int64_t, int64_t, int64_t, const double*
 typedef int (*trsm_fn)(nd4hip_handle*, int, int, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*);
 
 static int  (*p_device_count)(void);
+static int  (*p_create_multi)(nd4hip_handle**, const int*, int);
+static int  (*p_device_list)(nd4hip_handle*, int*, int);
 static int  (*p_create)(nd4hip_handle**, int);
 static void (*p_destroy)(nd4hip_handle*);
 static const char* (*p_last_error)(void);
@@ -88,6 +90,8 @@ static int load_library(void) {
 #define SYM(var, name) do { *(void**)(&var) = dlsym(g_lib, name); \
     if (!var) { snprintf(g_load_error, sizeof g_load_error, "symbol %s missing in %s", name, path); return -1; } } while (0)
   SYM(p_device_count, "nd4hip_device_count");
+  SYM(p_create_multi, "nd4hip_create_multi");
+  SYM(p_device_list, "nd4hip_device_list");
   SYM(p_create, "nd4hip_create");
   SYM(p_destroy, "nd4hip_destroy");
   SYM(p_last_error, "nd4hip_last_error");
@@ -126,6 +130,17 @@ static int load_library(void) {
 static int ensure_handle(napi_env env) {
   if (load_library() != 0) { napi_throw_error(env, "ND4HIP", g_load_error); return -1; }
   if (g_handle) return 0;
+  /* ND4HIP_DEVICES = "all" | "0,1,2,...": one handle over several GPUs; batched calls on host arrays are then sharded along the
+     leading batch axis (include/nd4hip.h, nd4hip_create_multi). Default: the single device ND4HIP_DEVICE (0). */
+  const char* list = getenv("ND4HIP_DEVICES");
+  if (list && *list) {
+    int ids[64], n = 0;
+    if (strcmp(list, "all") == 0) { const int cnt = p_device_count(); for (; n < cnt && n < 64; n++) ids[n] = n; }
+    else for (const char* q = list; *q && n < 64;) { ids[n++] = atoi(q); while (*q && *q != ',') q++; if (*q == ',') q++; }
+    if (n == 0) { napi_throw_error(env, "ND4HIP", "nd4hip: no HIP device available (ND4HIP_DEVICES)"); return -1; }
+    if (p_create_multi(&g_handle, ids, n) != 0) { napi_throw_error(env, "ND4HIP", p_last_error()); g_handle = NULL; return -1; }
+    return 0;
+  }
   int dev = 0;
   const char* e = getenv("ND4HIP_DEVICE");
   if (e && *e) dev = atoi(e);
@@ -213,6 +228,17 @@ static napi_value js_device_count(napi_env env, napi_callback_info info) {
   if (load_library() != 0) THROW(env, g_load_error);
   napi_create_int32(env, p_device_count(), &r);
   return r;
+}
+/* devices() -> [ids] behind the (lazily created) handle */
+static napi_value js_devices(napi_env env, napi_callback_info info) {
+  (void)info;
+  if (ensure_handle(env)) return NULL;
+  int ids[64];
+  const int n = p_device_list(g_handle, ids, 64);
+  napi_value arr, v;
+  napi_create_array_with_length(env, (size_t)n, &arr);
+  for (int i = 0; i < n && i < 64; i++) { napi_create_int32(env, ids[i], &v); napi_set_element(env, arr, (uint32_t)i, v); }
+  return arr;
 }
 static napi_value js_version(napi_env env, napi_callback_info info) {
   (void)info;
@@ -526,6 +552,7 @@ static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"device_count", NULL, js_device_count, NULL, NULL, NULL, napi_default, NULL},
     {"version", NULL, js_version, NULL, NULL, NULL, napi_default, NULL},
+    {"devices", NULL, js_devices, NULL, NULL, NULL, napi_default, NULL},
     {"dgemm_batched", NULL, js_dgemm, NULL, NULL, NULL, napi_default, NULL},
     {"dgetrf_batched", NULL, js_dgetrf, NULL, NULL, NULL, napi_default, NULL},
     {"dgeqrf_q_batched", NULL, js_dgeqrf, NULL, NULL, NULL, napi_default, NULL},

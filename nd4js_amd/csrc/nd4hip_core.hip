@@ -40,6 +40,11 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
+  }
   if (e != hipSuccess) { nd4hip_destroy(h); return nd4_hip_fail(e, "stream/event create", __FILE__, __LINE__); }
   h->stream = h->own_stream;
   *out = h;
@@ -48,7 +53,13 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
 
 extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   if (!h) return;
+  for (nd4hip_handle* p : h->peers) nd4hip_destroy(p);
+  h->peers.clear();
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   (void)hipSetDevice(h->device);
+  if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  for (int i = 0; i < 2; i++) { if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]); if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]); }
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (auto& b : h->ws) (void)hipFree(b.p);
   for (auto& b : h->stage) (void)hipFree(b.p);
@@ -58,6 +69,7 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
+  if (prev >= 0) (void)hipSetDevice(prev);
 }
 
 extern "C" int nd4hip_set_stream(nd4hip_handle* h, void* s) {

@@ -22,10 +22,12 @@ struct nd4hip_handle {
   size_t pinned_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_order = nullptr;      // orders the workspace arena across a change of stream (nd4hip_set_stream)
+  hipStream_t copy_stream = nullptr;  // H2D / D2H of the host-pointer entry points (overlaps the kernels on `stream`)
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_chunk[2] = {nullptr, nullptr};   // per staging set: inputs landed / kernels done
+  std::vector<nd4hip_handle*> peers;  // further devices of a multi-device handle (nd4hip_create_multi); owned
   int num_cu = 256;
   unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)
   int svd_sweeps = 0; unsigned long long svd_rotations = 0; double svd_offnorm = 0.0;   // audit of the last SVD call
-  bool host_io_pending = false;       // async H2D/D2H of a host-pointer call in flight (staging must not be reused before a sync)
 };
 
 // Makes h->device the calling thread's current HIP device for the duration of an entry point and restores the previous
@@ -93,6 +95,7 @@ int nd4_svdls(nd4hip_handle* h, int64_t batch, int64_t N, int64_t M, int64_t I, 
 int nd4_getrs(nd4hip_handle* h, int64_t batch, int64_t N, int64_t J, const double* LU, int64_t sLU, const int32_t* P, int64_t sP,
               const double* Y, int64_t sY, double* X);
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R);
+int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, double* T);
 int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
                      double* R, long ldr, long sR, const double* taus, long sTau, int* flips);
 int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* Tdiag, int bs, double* Q, int Lq);

@@ -1113,6 +1113,22 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
 //   lu_rule = true  (the c >= 0 branches for tall input, qr.js:97-139 / bidiag.js:49-61): every leading principal minor of
 //             Q's top L x L block is positive = positive pivots in its LU factorisation WITHOUT pivoting.
 // flips: L ints per matrix of scratch.
+// One panel factorisation on its own (the building block north_star's "HBM fraction on the QR panel" is quoted on):
+// A [batch, M, 16] -> R in the top 16 x 16 of A (in place), explicit unit-lower reflectors V [batch, M, 16], T [batch, 16, 16].
+int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, double* T) {
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NB, &p));
+  double* taus = static_cast<double*>(p);
+  const long sW = (long)M * NB;
+  const int nb = M < NB ? M : NB;
+  if (M <= 512)       launch_panel_row<1>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
+  else if (M <= 1024) launch_panel_row<2>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
+  else                launch_panel_row<4>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
+  ND4_HIP(hipGetLastError());
+  return 0;
+}
+
 int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
                      double* R, long ldr, long sR, const double* taus, long sTau, int* flips) {
   if (lu_rule) {

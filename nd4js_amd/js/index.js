@@ -565,5 +565,6 @@ module.exports = Object.assign(standalone, {
   NDArray, DeviceNDArray, install, bcastGroups,
   accelerated: a => !!a && (isDev(a) || a.data instanceof Float64Array || a.data instanceof Int32Array),
   device_count: () => native().device_count(),
+  devices: () => native().devices(),            // ids behind the handle (ND4HIP_DEVICES=all|0,1,...: batched host calls are sharded)
   version: () => native().version(),
 });

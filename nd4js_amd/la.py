@@ -58,7 +58,9 @@ def _bcast_groups(lead, la, lb, IK, KJ):
     return groups
 
 
-def matmul2(a, b, device=None):
+def matmul2(a, b, device=None, out=None):
+    """`out`: optional preallocated C-contiguous float64 result (a fresh 128 MiB array costs 8-15 ms of page faults on its first
+    write — the OS's price, tools/pcie_fresh.hip — which a caller that reuses buffers does not pay)."""
     a = _asarray(a, "matmul2(a,b)")
     b = _asarray(b, "matmul2(a,b)")
     if a.ndim < 2:
@@ -73,7 +75,9 @@ def matmul2(a, b, device=None):
         lead = np.broadcast_shapes(a.shape[:-2], b.shape[:-2])
     except ValueError:
         raise ValueError("Shapes are not broadcast-compatible.")
-    c = np.empty(tuple(lead) + (I, J), dtype=np.float64)
+    c = np.empty(tuple(lead) + (I, J), dtype=np.float64) if out is None else out
+    if c.shape != tuple(lead) + (I, J) or c.dtype != np.float64 or not c.flags.c_contiguous:
+        raise ValueError("matmul2(a,b,out): out must be a C-contiguous float64 array of shape %r" % (tuple(lead) + (I, J),))
     h = _lib.handle(device)
     for cnt, offA, sA, offB, sB, offC in _bcast_groups(tuple(lead), a.shape[:-2], b.shape[:-2], I * K, K * J):
         _lib.check(h.lib.nd4hip_dgemm_batched(

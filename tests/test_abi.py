@@ -86,3 +86,20 @@ def test_broadcast_grouping_covers_every_batch_member():
                 assert a_idx[offC + k] == offA + k * sA and b_idx[offC + k] == offB + k * sB
             seen += cnt
         assert seen == a_idx.size
+
+
+def test_partition_matches_the_rank_sharding_and_is_complete():
+    """nd4hip_partition (devices of one multi-device handle) and nd4js_amd.dist.shard (one process per GPU) cut a batch the same
+    way: contiguous blocks, sizes within one of each other, nothing lost, devices beyond the batch idle."""
+    from nd4js_amd import _lib
+    from nd4js_amd.dist import shard
+    for batch in (0, 1, 2, 5, 7, 8, 1023, 1024):
+        for n_dev in (1, 2, 3, 8):
+            blocks = [_lib.partition(batch, n_dev, i) for i in range(n_dev)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == batch
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            used = [s for s in sizes if s]
+            assert sum(sizes) == batch and (not used or max(used) - min(used) <= 1)
+            if batch >= n_dev:
+                assert blocks == [shard(batch, n_dev, r) for r in range(n_dev)]
