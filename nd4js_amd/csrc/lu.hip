@@ -128,8 +128,11 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
+  // The column loop is expanded at compile time (a generic lambda called with integral constants), not by the loop unroller:
+  // the DPP cross-lane moves are convergent operations, a loop that contains them is only unrolled late, after the pass that
+  // splits the register tile into scalars has run, and the tile would then live in scratch memory.
+  auto column = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     if (k < nb) {                                        // uniform
       const int jc = j0 + k;
       // ---- arg-max of |column k| over rows >= jc ----
@@ -141,46 +144,43 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
         if (r < jc || r >= N) o.mag = -2.0;
         cand = better(cand, o);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        PivCand o;
-        o.mag = __shfl_xor(cand.mag, off);
-        o.idx = __shfl_xor(cand.idx, off);
-        cand = better(cand, o);
-      }
-      if ((t & 63) == 0) s_red[wave] = cand;
+      // wave arg-max on DPP (VALU speed; a ds_bpermute butterfly is six dependent LDS-crossbar round trips): the largest
+      // magnitude first, then the lowest row among the lanes that hold it (first maximum, lu.js:50-52)
+      const double wm = nd4dpp::wave_max(cand.mag);
+      const int wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
+      if ((t & 63) == 0) { s_red[wave].mag = wm; s_red[wave].idx = wi; }
       __syncthreads();
-      PivCand best = s_red[0];
-#pragma unroll
-      for (int w = 1; w < 8; w++) best = better(best, s_red[w]);
-      const int piv = nopivot ? jc : best.idx;
+      // the 8 wave candidates: lane l reads candidate l & 7, three DPP steps leave the block result in every lane
+      const PivCand c8 = s_red[t & 7];
+      double bm = fmax(c8.mag, nd4dpp::xor1(c8.mag)); bm = fmax(bm, nd4dpp::xor2(bm)); bm = fmax(bm, nd4dpp::xor4(bm));
+      int bi = c8.mag == bm ? c8.idx : 0x7fffffff;
+      bi = min(bi, nd4dpp::xor1(bi)); bi = min(bi, nd4dpp::xor2(bi)); bi = min(bi, nd4dpp::xor4(bi));
+      const int piv = nopivot ? jc : bi;               // (kept in a VGPR: a scalar row index would turn the `i == pi` selects below
+                                                       //  into a dynamically indexed register tile, i.e. scratch memory)
       if (t == 0) {
         ip[jc] = piv;
         }
       // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
-      const int pt = (piv - j0) & 511, pi = (piv - j0) >> 9;
-      if (t == pt) {
+      // (each row slot tests its own row number: a slot index derived from piv would let the optimiser turn the tile into a
+      //  dynamically indexed array, i.e. scratch memory)
 #pragma unroll
-        for (int i = 0; i < R; i++)
-          if (i == pi) {
+      for (int i = 0; i < R; i++)
+        if (j0 + t + 512 * i == piv) {
 #pragma unroll
-            for (int c = 0; c < NB; c++) s_u[c] = a[i][c];
-          }
-      }
+          for (int c = 0; c < NB; c++) s_u[c] = a[i][c];
+        }
       if (t == k) {
 #pragma unroll
         for (int c = 0; c < NB; c++) s_j[c] = a[0][c];
       }
       __syncthreads();
       if (piv != jc) {
-        if (t == pt) {
 #pragma unroll
-          for (int i = 0; i < R; i++)
-            if (i == pi) {
+        for (int i = 0; i < R; i++)
+          if (j0 + t + 512 * i == piv) {
 #pragma unroll
-              for (int c = 0; c < NB; c++) a[i][c] = s_j[c];
-            }
-        }
+            for (int c = 0; c < NB; c++) a[i][c] = s_j[c];
+          }
         if (t == k) {
 #pragma unroll
           for (int c = 0; c < NB; c++) a[0][c] = s_u[c];
@@ -188,11 +188,17 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
       }
       // ---- eliminate below the pivot ----
       const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
+      const double pk = u[k];
+      const double rk = (pk == 0.0 || pk != pk || __builtin_isinf(pk)) ? 1.0 / pk : nd4dpp::fast_rcp(pk);   // 0, Inf, NaN pivots: IEEE semantics
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 512 * i;
         if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
-          const double l = a[i][k] / u[k];               // lu.js:68
+          // a / pivot (lu.js:68) as a * (1/pivot) with one residual correction: the quotient of a division that comes out
+          // exact (integer-valued and structured inputs, where later pivot TIES depend on it) is reproduced exactly, any other
+          // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division
+          const double q0 = a[i][k] * rk;
+          const double l = fma(fma(-q0, pk, a[i][k]), rk, q0);
           a[i][k] = l;
 #pragma unroll
           for (int c = k + 1; c < NB; c++) a[i][c] -= l * u[c];   // lu.js:71-72
@@ -200,7 +206,11 @@ __global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int
       }
     }
     __builtin_amdgcn_sched_barrier(0);                   // keep the unrolled columns from interleaving (VGPR pressure)
-  }
+  };
+#define ND4_COL(K) column(std::integral_constant<int, K>{});
+  ND4_COL(0) ND4_COL(1) ND4_COL(2) ND4_COL(3) ND4_COL(4) ND4_COL(5) ND4_COL(6) ND4_COL(7)
+  ND4_COL(8) ND4_COL(9) ND4_COL(10) ND4_COL(11) ND4_COL(12) ND4_COL(13) ND4_COL(14) ND4_COL(15)
+#undef ND4_COL
 #pragma unroll
   for (int i = 0; i < R; i++) {
     const int r = j0 + t + 512 * i;
@@ -415,8 +425,17 @@ __global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, in
 // ---- apply the panel's row swaps to the columns outside the panel, and (fused) U12 = L11^-1 A12 for the columns to
 // its right: both are one-thread-per-column jobs over the same columns, and the 16 swapped-in pivot rows are exactly the
 // rows the triangular solve works on, so they never leave the registers in between. One launch per panel instead of two.
+__global__ void lu_iota(int32_t* __restrict__ P, long total, int N) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < total) P[i] = (int32_t)(i % N);
+}
+// Pm != NULL: thread 0 of the first workgroup also carries the permutation vector through the panel's interchanges, as one more
+// "column" (lu.js:59-61 swaps P together with the rows). Rebuilding P from all interchanges at the end was one thread walking a
+// 2048-step dependent chain: 155 us, 2 % of the whole factorisation. (Composing the nb interchanges into one gather/scatter so
+// that a column's loads are independent was tried: 11.0 us per launch against 9.7 us — the kernel is bound by its launch and
+// 8 workgroups of latency, not by the chain.)
 __global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, long strideM, int j0, int nb, const int32_t* __restrict__ ipiv,
-                                                int do_swap) {
+                                                int do_swap, int32_t* __restrict__ Pm) {
   __shared__ double s_l[NB][NB + 1];
   __shared__ int s_piv[NB];
   double* A = LU + blockIdx.y * strideM;
@@ -428,6 +447,13 @@ __global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, 
     if (t < NB) s_piv[t] = (t < nb) ? ip[j0 + t] : j0 + t;
   }
   __syncthreads();
+  if (Pm != nullptr && do_swap && blockIdx.x == 0 && t == 255) {     // the permutation vector rides along as one more column
+    int32_t* P = Pm + (long)blockIdx.y * N;
+    for (int k = 0; k < nb; k++) {
+      const int r = j0 + k, pv = s_piv[k];
+      if (pv != r) { const int32_t x = P[r]; P[r] = P[pv]; P[pv] = x; }
+    }
+  }
   int col = blockIdx.x * blockDim.x + t;                   // index among the N - nb outside columns
   if (col >= N - nb) return;
   const bool right = col >= j0;
@@ -520,6 +546,9 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   ND4_TRY(nd4_ws_alloc(h, sizeof(int32_t) * total, &ws));
   int32_t* ipiv = static_cast<int32_t*>(ws);
 
+  // every panel of a matrix wider than one panel is followed by lu_laswp: P then rides along with it
+  const bool p_in_laswp = N > NB;
+  if (p_in_laswp) hipLaunchKernelGGL(lu_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, (int)N);
   static const bool tall8_off = [] { const char* e = getenv("ND4HIP_LU_NO_TALL8"); return e && *e && *e != '0'; }();
   for (int j0 = 0, step = NB; j0 < N; j0 += step) {
     const int m = N - j0;
@@ -550,7 +579,7 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     const int rest = N - j0 - nb;
     if (N > nb && (!nopivot || rest > 0))
       hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                         LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1);
+                         LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1, p_in_laswp ? P : (int32_t*)nullptr);
     if (rest > 0) {
       ND4_HIP(hipGetLastError());
       double* base = LU;
@@ -560,6 +589,7 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
                        1.0, base + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
     }
   }
+  if (p_in_laswp) { ND4_HIP(hipGetLastError()); return 0; }
   if ((size_t)N * sizeof(int32_t) <= 60 * 1024)
     hipLaunchKernelGGL(lu_build_perm, dim3((unsigned)batch), dim3(256), (size_t)N * sizeof(int32_t), h->stream, P, ipiv, N, nopivot);
   else
