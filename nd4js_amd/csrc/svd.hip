@@ -281,12 +281,14 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
   hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, svr, N, tol2, floor2);
   int sweeps = 0;
-  unsigned long long last_off = 0;
+  unsigned long long last_off = 0, rot_seen = 0;
+  // the first sweep of a large matrix rotates (nearly) every pair; afterwards the rotation count of the last sweep decides
+  bool dense_phase = blocked && Np >= 512 && !getenv("ND4HIP_JAC_PRECHECK_ALWAYS");
   if (N > 1) {
     for (;;) {
       ND4_HIP(hipMemsetAsync(active, 0, 16, h->stream));            // active + offmax (the rotation total runs on)
       if (blocked) {
-        ND4_TRY(nd4_jacobi_block_sweep(h, batch, Np, Wb, Utb, st, floor2, tol2, offmax, bscratch));
+        ND4_TRY(nd4_jacobi_block_sweep(h, batch, Np, Wb, Utb, st, floor2, tol2, offmax, bscratch, dense_phase));
       } else {
         for (int s = 0; s < n2 - 1; s++)
           hipLaunchKernelGGL(jac_step, dim3((unsigned)(n2 / 2), (unsigned)batch), dim3(256), 0, h->stream,
@@ -308,6 +310,12 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       }
       if (h_active[0] == 0) { last_off = *h_off; break; }
       last_off = *h_off;
+      {
+        const unsigned long long in_sweep = h_off[1] - rot_seen;                  // rotations of the sweeps since the last read-back
+        rot_seen = h_off[1];
+        dense_phase = dense_phase && check_every == 1 &&
+                      (double)in_sweep > 0.25 * (double)h_active[0] * 0.5 * (double)N * (double)(N - 1);
+      }
       if (sweeps >= MAX_SWEEPS) break;
       if (getenv("ND4HIP_SVD_MAXSWEEPS") && sweeps >= atoi(getenv("ND4HIP_SVD_MAXSWEEPS"))) break;    // timing experiments only
     }

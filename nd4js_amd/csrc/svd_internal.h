@@ -20,4 +20,5 @@ __host__ __device__ __forceinline__ void nd4_rr_pair(int n2, int s, int i, int& 
 // scratch must hold nd4_jacobi_block_scratch_doubles(batch, N) doubles.
 size_t nd4_jacobi_block_scratch_doubles(int batch, int N);
 int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double* Ut, JacState* st,
-                           const double* floor2, double tol2, unsigned long long* offmax, double* scratch);
+                           const double* floor2, double tol2, unsigned long long* offmax, double* scratch, bool dense_phase);
+// dense_phase: the previous sweep rotated most pairs (the driver knows from the rotation count): skip the per-visit pre-check
