@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 // ---- rank-k update kernel: K <= 32, A not transposed --------------------------------------------------------------
 // The trailing updates of LU / QR / Cholesky / LDL and of the blocked triangular solves are C (+)= alpha A op(B) with
 // K = 16 or 32: two K-steps of the tiled kernel above, whose fixed cost (LDS staging, barriers, one workgroup per CU
-// at 2048^2) is then most of the launch. Here nothing is staged: every wave owns 32 x 64 of C (2 x 4 accumulators),
+// at 2048^2) is then most of the launch. Here nothing is staged: every wave owns 16 x 32 of C (SK_RT x SK_CT = 1 x 2 accumulators),
 // reads its A rows and the B panel straight from global memory in MFMA operand layout (cache-line-complete, the four
 // waves of a workgroup share the B panel through L1/L2), starts the accumulators at (beta/alpha) C (exact for the
 // alpha = +-1, beta in {0, +-1} these callers use; other combinations take the tiled kernel), and writes alpha * acc.
-// No LDS, no barrier, 2 workgroups of 128 x 64 per CU: the launch is bound by the read-modify-write of C.
+// No LDS, no barrier, workgroups of 64 x 32 (4 waves): the launch is bound by the read-modify-write of C.
 constexpr int SK_RT = 1;                                   // 16-row MFMA tiles per wave
 constexpr int SK_CT = 2;                                   // 16-column MFMA tiles per wave
 constexpr int SK_BM = 4 * 16 * SK_RT, SK_BN = 16 * SK_CT, SK_KSTEPS = 8;

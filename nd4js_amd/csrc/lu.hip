@@ -6,7 +6,7 @@
 //              wave-shuffle + LDS arg-max (ties -> lowest row, exactly the reference's strict '>' scan,
 //              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. lu_panel_row<R>: one thread per
 //              row, the R x 16 tile of each lane in registers (m <= 2048); lu_panel_row_wt<R,W,T>: the same on
-//              1024 threads with 8- / 4-column panels (m <= 4096 / 8192); lu_panel_reg / lu_panel_global: 16 lanes
+//              1024 threads with 8- / 4-column panels (m <= 4096 / 8192); lu_panel_global: 16 lanes
 //              per row / panel in global memory (anything taller).
 //   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61 swaps full
 //              rows) and, in the same pass, U12 = L11^-1 * A12 for the columns to the right (unit lower
@@ -21,7 +21,6 @@
 namespace {
 
 constexpr int NB = 16;          // panel width == lanes per row
-constexpr int RMAX = 48;        // register-resident rows per lane group (m <= 64 groups * 48 = 3072)
 
 struct PivCand { double mag; int idx; };
 
@@ -343,85 +342,6 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
   }
 }
 
-// ---- fast panel kernel: the panel (m <= 64*RMAX rows x 16 cols) lives in registers -------------
-// lane group g (16 lanes) owns rows j0 + g + 64*i; lane c of the group owns column j0 + c.
-template <int R>
-__global__ __launch_bounds__(1024) void lu_panel_reg(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
-  __shared__ PivCand s_red[16];
-  __shared__ int s_piv;
-  __shared__ double s_u[NB], s_j[NB];
-  double* A = LU + blockIdx.x * strideM;
-  int32_t* ip = ipiv + (long)blockIdx.x * N;
-  const int t = threadIdx.x, T = 1024;
-  const int c = t & (NB - 1), g = t >> 4;
-  const bool col_ok = c < nb;
-
-  double a[R];
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + g + 64 * i;
-    a[i] = (r < N && col_ok) ? A[(long)r * N + j0 + c] : 0.0;
-  }
-
-  // Rows beyond N hold zeros: they can never win the arg-max against a valid row (lower index wins
-  // ties) and are never stored, so the inner loops carry no per-row bounds predicate. Only slot 0
-  // (rows j0 + g, g < 64) can contain already-factored rows (k < 16 <= 64).
-  for (int k = 0; k < nb; k++) {
-    const int jc = j0 + k;
-    // arg-max over column k: held by lanes c == k
-    PivCand cand{-2.0, 0x7fffffff};
-    if (c == k) {
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + g + 64 * i;
-        PivCand o{pivot_mag(a[i], r, jc), r};
-        if (i == 0 && g < k) o.mag = -2.0;
-        if (r >= N) o.mag = -2.0;
-        cand = better(cand, o);
-      }
-    }
-    int piv = block_argmax(cand, s_red, &s_piv, t, T);
-    if (nopivot) piv = jc;
-    if (t == 0) {
-      ip[jc] = piv;
-    }
-    // publish the pivot row (its owner group) and, if it moves, the displaced row jc
-    const int pg = (piv - j0) & 63, pi = (piv - j0) >> 6;     // owner group / slot of row piv
-    double mine_piv = a[0];
-#pragma unroll
-    for (int i = 1; i < R; i++) mine_piv = (i == pi) ? a[i] : mine_piv;
-    if (g == pg && col_ok) s_u[c] = mine_piv;
-    if (g == k && col_ok) s_j[c] = a[0];                      // row jc = j0 + k lives in group k, slot 0
-    __syncthreads();
-    if (piv != jc) {                                          // swap rows jc <-> piv inside the panel
-      const double from_jc = s_j[c], from_piv = s_u[c];
-      if (g == pg) {
-#pragma unroll
-        for (int i = 0; i < R; i++) a[i] = (i == pi) ? from_jc : a[i];
-      }
-      if (g == k) a[0] = from_piv;
-    }
-    const double pv = s_u[k], uc = s_u[c];
-    {                                                         // slot 0: rows j0+g, only g > k are below the pivot
-      const double l = __shfl(a[0], (threadIdx.x & 48) | k, 64) / pv;
-      const double upd = (c == k) ? l : ((c > k) ? a[0] - l * uc : a[0]);
-      a[0] = (g > k) ? upd : a[0];
-    }
-#pragma unroll
-    for (int i = 1; i < R; i++) {
-      const double l = __shfl(a[i], (threadIdx.x & 48) | k, 64) / pv;
-      a[i] = (c == k) ? l : ((c > k) ? a[i] - l * uc : a[i]);
-    }
-    __syncthreads();       // s_u / s_j / s_red reused next column
-  }
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + g + 64 * i;
-    if (r < N && col_ok) A[(long)r * N + j0 + c] = a[i];
-  }
-}
-
 // ---- apply the panel's row swaps to the columns outside the panel, and (fused) U12 = L11^-1 A12 for the columns to
 // its right: both are one-thread-per-column jobs over the same columns, and the 16 swapped-in pivot rows are exactly the
 // rows the triangular solve works on, so they never leave the registers in between. One launch per panel instead of two.
@@ -523,10 +443,6 @@ template <int R>
 void launch_panel_row(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
   hipLaunchKernelGGL((lu_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
 }
-template <int R>
-void launch_panel_reg(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
-  hipLaunchKernelGGL((lu_panel_reg<R>), dim3(batch), dim3(1024), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
-}
 
 }  // namespace
 
@@ -549,13 +465,12 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   // every panel of a matrix wider than one panel is followed by lu_laswp: P then rides along with it
   const bool p_in_laswp = N > NB;
   if (p_in_laswp) hipLaunchKernelGGL(lu_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, (int)N);
-  static const bool tall8_off = [] { const char* e = getenv("ND4HIP_LU_NO_TALL8"); return e && *e && *e != '0'; }();
   for (int j0 = 0, step = NB; j0 < N; j0 += step) {
     const int m = N - j0;
     // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
     // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
-    const bool tall8 = !tall8_off && m > 2048 && m <= 4096;
-    const bool tall4 = !tall8_off && m > 4096 && m <= 8192;
+    const bool tall8 = m > 2048 && m <= 4096;
+    const bool tall4 = m > 4096 && m <= 8192;
     step = tall8 ? 8 : tall4 ? 4 : NB;
     const int nb = N - j0 < step ? N - j0 : step;
     if (tall8) {
@@ -566,12 +481,6 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
       if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
       else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
       else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-    } else if (m > 2048 && m <= 64 * RMAX) {
-      const int R = (m + 63) / 64;
-      if (R <= 8)       launch_panel_reg<8>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      else if (R <= 16) launch_panel_reg<16>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      else if (R <= 32) launch_panel_reg<32>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      else              launch_panel_reg<RMAX>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
     } else {
       int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
       hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);

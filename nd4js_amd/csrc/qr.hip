@@ -1041,9 +1041,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   // ---- factorisation: panels left to right ----
   for (int pnl = 0; pnl < npanels; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
-    const int Rn = (m + 63) / 64;
-    static const bool tall8_off = [] { const char* e = getenv("ND4HIP_QR_NO_TALL8"); return e && *e && *e != '0'; }();
-    if (!tall8_off && m > 2048 && m <= 8192) {
+    if (m > 2048 && m <= 8192) {
       // the 16-column slot in parts on 1024 threads: two 8-column halves (m <= 4096: 4 rows x 8 columns per lane) or four
       // 4-column quarters (m <= 8192: 8 rows x 4 columns per lane). After each part its reflectors are applied to the rest
       // of the slot (the live T holds only that part's block); at the end T is assembled from the side blocks and V^T V.
@@ -1068,11 +1066,6 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     if (m <= 512)       launch_panel_row<1>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (m <= 1024) launch_panel_row<2>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else if (m <= 2048) launch_panel_row<4>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (Rn <= 4)        launch_panel<4, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (Rn <= 8)   launch_panel<8, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (Rn <= 16)  launch_panel<16, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (Rn <= 32)  launch_panel<32, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (Rn <= RMAX) launch_panel<RMAX, true>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     ND4_HIP(hipGetLastError());
     // trailing columns: C <- H^T C = (I - V T^T V^T) C

@@ -237,7 +237,10 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   // zero column stays zero under row rotations, so the leading N x N parts of W and Ut evolve exactly as they would alone
   // (Ut' = diag(Ut, I)) and are copied back before the epilogue. (The row-pair kernel it replaces there is 4-6x slower:
   // N = 1000 took 222 ms against 39 ms at 1024.)
-  const bool noblock = getenv("ND4HIP_SVD_NOBLOCK") != nullptr;
+  // environment switches are read once per process (never inside the sweep loop)
+  static const bool noblock = getenv("ND4HIP_SVD_NOBLOCK") != nullptr;
+  static const bool precheck_always = getenv("ND4HIP_JAC_PRECHECK_ALWAYS") != nullptr;
+  static const bool debug = getenv("ND4HIP_SVD_DEBUG") != nullptr;
   const bool blocked = N >= 16 && !noblock;      // below 16 the row-pair kernel is fine (a few microseconds per matrix)
   const int Np = blocked ? ((N + 63) / 64) * 64 : N;
   const bool padded = Np != N;
@@ -283,7 +286,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   int sweeps = 0;
   unsigned long long last_off = 0, rot_seen = 0;
   // the first sweep of a large matrix rotates (nearly) every pair; afterwards the rotation count of the last sweep decides
-  bool dense_phase = blocked && Np >= 512 && !getenv("ND4HIP_JAC_PRECHECK_ALWAYS");
+  bool dense_phase = blocked && Np >= 512 && !precheck_always;
   if (N > 1) {
     for (;;) {
       ND4_HIP(hipMemsetAsync(active, 0, 16, h->stream));            // active + offmax (the rotation total runs on)
@@ -304,7 +307,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       if (sweeps % check_every != 0 && sweeps < MAX_SWEEPS) continue;
       ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));   // active, offmax, rotation total
       ND4_HIP(hipStreamSynchronize(h->stream));
-      if (getenv("ND4HIP_SVD_DEBUG")) {
+      if (debug) {
         double r; unsigned long long bb = *h_off; memcpy(&r, &bb, 8);
         fprintf(stderr, "[nd4hip svd] sweep %d: active matrices %u, max |cos| rotated %.3e\n", sweeps, h_active[0], sqrt(r));
       }
@@ -317,7 +320,6 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
                       (double)in_sweep > 0.25 * (double)h_active[0] * 0.5 * (double)N * (double)(N - 1);
       }
       if (sweeps >= MAX_SWEEPS) break;
-      if (getenv("ND4HIP_SVD_MAXSWEEPS") && sweeps >= atoi(getenv("ND4HIP_SVD_MAXSWEEPS"))) break;    // timing experiments only
     }
   }
   if (padded) {

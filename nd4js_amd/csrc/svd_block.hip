@@ -26,8 +26,7 @@ namespace {
 constexpr int BB = 32;         // rows per block
 constexpr int PB = 64;         // rows per block pair
 constexpr int CH = 256;        // columns per workgroup (gram and apply)
-constexpr int MAX_INNER_DEFAULT = 1;   // inner Jacobi sweeps per visit of a pair (measured: the outer sweep count does not
-                                       // depend on it, 15-16 at N=2048 for 1, 2 and 4)
+// One inner Jacobi sweep per visit of a pair (measured: the outer sweep count does not depend on it, 15-16 at N=2048 for 1, 2, 4).
 
 // wave-uniform broadcast of lane K's value through SGPRs (v_readlane_b32): no LDS traffic, unlike __shfl
 template <int K> __device__ __forceinline__ int bcast_i(int v) { return __builtin_amdgcn_readlane(v, K); }
@@ -148,24 +147,30 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   for (int e = threadIdx.x; e < PB * PB; e += 256) G[e] = s_g[e / PB][e % PB];
 }
 
-// FUSED: the workgroup computes the Gram matrix of its block pair itself (small N: the MFMA phase of one
-// workgroup overlaps the LDS-bound rotation rounds of the other workgroup on the CU, and the partial-Gram
-// round trip through HBM disappears); Gpart then carries W and nchunks carries N.
-template <bool FUSED>
-__global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+// Two-phase rotation rounds (row phase, barrier, column phase, barrier) on the 64 x 64 Gram matrix in LDS: the full sweep of
+// step 0 and the mid-size batches. PW = pairs of a round per wave: 8 -> 4 waves (throughput: many workgroups per CU), 2 -> 16
+// waves (2048^2: 115.7 ms with 4 waves, 98.1 with 8, 95.0 with 16 when this kernel ran every step).
+// FUSED: the workgroup computes the Gram matrix of its block pair itself (small N: the MFMA phase of one workgroup overlaps the
+// LDS-bound rotation rounds of the other workgroup on the CU, and the partial-Gram round trip through HBM disappears); Gpart
+// then carries W and nchunks carries N.
+// The rounds are LDS-latency bound (read 2 rows / 2 columns, rotate, write back, barrier), and with only nblk/2 workgroups
+// in flight for a single large matrix the chip is mostly idle: twice the waves per workgroup hide that latency better.
+template <bool FUSED, int PW>
+__global__ __launch_bounds__(2048 / PW) void jacb_eigen(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                                    JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
                                                    double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
                                                    unsigned long long* __restrict__ offmax, int max_inner, int cross_only) {
   __shared__ double G[PB][PB + 1];
   __shared__ double Q[PB][PB + 1];
-  __shared__ unsigned s_rot[4];
+  __shared__ unsigned s_rot[32 / PW];
   const int pairIdx = blockIdx.x, mat = blockIdx.y;
   if (st[mat].done) return;
   int I, J;
   nd4_rr_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (FUSED) {
+  if constexpr (FUSED) {
+    static_assert(!FUSED || PW == 8, "the fused Gram phase is written for 4 waves");
     const int N = nchunks, fx = lane & 15, fk = lane >> 4;
     const double* W = Gpart + mat * sG_mat;
     const double* rp[4];
@@ -179,126 +184,8 @@ __global__ __launch_bounds__(256) void jacb_eigen(const double* __restrict__ Gpa
     const int per = ((N + 63) / 64) * 16;                     // columns per wave, multiple of 16
     gram_accumulate(acc, rp, wave * per, per, N, fk);
     gram_reduce_lds<PB + 1>(G, acc, wave, fk, fx);
-    for (int e = t; e < PB * PB; e += 256) Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+    for (int e = t; e < PB * PB; e += 2048 / PW) Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
   } else {
-    const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
-    for (int e = t; e < PB * PB; e += 256) {
-      double s = 0.0;
-      for (int ch = 0; ch < nchunks; ch++) s += Gp[(long)ch * (PB * PB) + e];
-      G[e / PB][e % PB] = s;
-      Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
-    }
-  }
-  __syncthreads();
-  const double fl = floor2[mat];
-  unsigned total = 0;
-  double relmax = 0.0;
-  // converged pairs (the common case in the last sweeps) leave after one pass over the off-diagonal
-  {
-    int need = 0;
-    for (int e = t; e < PB * PB; e += 256) {
-      const int i = e / PB, j = e % PB;
-      if (i < j) { const double a = G[i][i], b = G[j][j], g = G[i][j]; need |= (a > fl) && (b > fl) && (g * g > tol2 * a * b); }
-    }
-    need = __syncthreads_or(need);
-    if (!need) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
-  }
-  // cross_only: the two blocks were orthogonalised internally on earlier visits of this sweep, so only the
-  // 32 x 32 pairs (p in I, q in J) are visited: 32 rounds of 32 disjoint pairs (i, 32 + (i + r) % 32).
-  const int nrounds = cross_only ? BB : PB - 1;
-  for (int inner = 0; inner < max_inner; inner++) {
-    unsigned rot = 0;
-    for (int r = 0; r < nrounds; r++) {
-      int p, q;
-      if (cross_only) { p = wave * 8 + (lane & 7); q = BB + ((p + r) & (BB - 1)); }
-      else nd4_rr_pair(PB, r, wave * 8 + (lane & 7), p, q);
-      const double a = G[p][p], b = G[q][q], g = G[p][q];
-      const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
-      double c = 1.0, s = 0.0;                              // kept as (s, tau = tan(theta/2)): see svd.hip jac_step
-      if (go) {
-        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (b-a)/(2g), rewritten without the division by g
-        const double d = b - a, hh = 2.0 * g, rr = d * d + hh * hh;
-        const double root = rr * fast_rsqrt(rr);
-        const double tn = (((d < 0.0) != (g < 0.0)) ? -fabs(hh) : fabs(hh)) * fast_rcp(fabs(d) + root);
-        const double cc = fast_rsqrt(1.0 + tn * tn);
-        s = cc * tn;
-        c = s * fast_rcp(1.0 + cc);                        // c now holds tau = tan(theta/2)
-        relmax = fmax(relmax, (g * g) / (a * b));
-      }
-      rot += (unsigned)__popcll(__ballot(go && lane < 8));
-      // wave-uniform rotation parameters of this wave's 8 pairs (SGPRs)
-      double sk[8], ck[8]; int pk[8], qk[8];
-#define ND4_BC(K) sk[K] = bcast_d<K>(s); ck[K] = bcast_d<K>(c); pk[K] = bcast_i<K>(p); qk[K] = bcast_i<K>(q);
-      ND4_BC(0) ND4_BC(1) ND4_BC(2) ND4_BC(3) ND4_BC(4) ND4_BC(5) ND4_BC(6) ND4_BC(7)
-#undef ND4_BC
-      // ---- row phase: rows p,q of G and of Q (lane = column). The 8 pairs touch disjoint rows, so all
-      // 32 reads are issued before the first write (the compiler cannot prove that by itself and would
-      // serialise read->fma->write eight times: this loop is LDS-latency bound, not bandwidth bound).
-      // An idle pair (s = 0) rewrites its rows unchanged.
-      {
-        double gp[8], gq[8], up[8], uq[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { gp[k] = G[pk[k]][lane]; gq[k] = G[qk[k]][lane]; up[k] = Q[pk[k]][lane]; uq[k] = Q[qk[k]][lane]; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          G[pk[k]][lane] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
-          G[qk[k]][lane] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
-          Q[pk[k]][lane] = up[k] - sk[k] * (uq[k] + ck[k] * up[k]);
-          Q[qk[k]][lane] = uq[k] + sk[k] * (up[k] - ck[k] * uq[k]);
-        }
-      }
-      __syncthreads();
-      // ---- column phase: columns p,q of G (lane = row) ----
-      {
-        double gp[8], gq[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { gp[k] = G[lane][pk[k]]; gq[k] = G[lane][qk[k]]; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          G[lane][pk[k]] = gp[k] - sk[k] * (gq[k] + ck[k] * gp[k]);
-          G[lane][qk[k]] = gq[k] + sk[k] * (gp[k] - ck[k] * gq[k]);
-        }
-      }
-      __syncthreads();
-    }
-    if (lane == 0) s_rot[wave] = rot;
-    __syncthreads();
-    const unsigned tot = s_rot[0] + s_rot[1] + s_rot[2] + s_rot[3];
-    __syncthreads();
-    total += tot;
-    if (tot == 0) break;
-  }
-  double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
-  if (total) for (int e = t; e < PB * PB; e += 256) Qt[e] = Q[e / PB][e % PB];
-  // max over the wave of the largest cos^2 that triggered a rotation
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) relmax = fmax(relmax, __shfl_xor(relmax, off));
-  if (lane == 0 && relmax > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(relmax));
-  if (t == 0) {
-    flags[mat * sF_mat + pairIdx] = total ? 1 : 0;
-    if (total) atomicAdd(&st[mat].rotations, total);
-  }
-}
-
-// The same rotation rounds on 8 or 16 waves (512 / 1024 threads): each wave carries 4 or 2 of the 32 disjoint pairs of a
-// round instead of 8 (2048^2: 115.7 ms with 4 waves, 98.1 with 8, 95.0 with 16).
-// The rounds are LDS-latency bound (read 2 rows / 2 columns, rotate, write back, barrier), and with only nblk/2 workgroups
-// in flight for a single large matrix the chip is mostly idle: twice the waves per workgroup hide that latency better.
-template <int PW>                                      // pairs per wave: 4 -> 8 waves, 2 -> 16 waves
-__global__ __launch_bounds__(2048 / PW) void jacb_eigen8(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
-                                                   JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
-                                                   double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                   unsigned long long* __restrict__ offmax, int max_inner, int cross_only) {
-  __shared__ double G[PB][PB + 1];
-  __shared__ double Q[PB][PB + 1];
-  __shared__ unsigned s_rot[32 / PW];
-  const int pairIdx = blockIdx.x, mat = blockIdx.y;
-  if (st[mat].done) return;
-  int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
-  if (J >= nblk) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  {
     const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
     for (int e = t; e < PB * PB; e += 2048 / PW) {
       double s = 0.0;
@@ -349,6 +236,7 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen8(const double* __restric
 #define ND4_BC(K) sk[K] = bcast_d<K>(s); ck[K] = bcast_d<K>(c); pk[K] = bcast_i<K>(p); qk[K] = bcast_i<K>(q);
       ND4_BC(0) ND4_BC(1)
       if constexpr (PW > 2) { ND4_BC(2) ND4_BC(3) }
+      if constexpr (PW > 4) { ND4_BC(4) ND4_BC(5) ND4_BC(6) ND4_BC(7) }
 #undef ND4_BC
       // ---- row phase: rows p,q of G and of Q (lane = column). The 8 pairs touch disjoint rows, so all
       // 32 reads are issued before the first write (the compiler cannot prove that by itself and would
@@ -400,208 +288,33 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen8(const double* __restric
   }
 }
 
-// ---- cross-only rotation rounds with ONE barrier per round ------------------------------------------------------------
-// The 32 rounds of a cross-only visit are a dependent chain (the angles of round r+1 need the Gram matrix after round r),
-// so the visit costs 32 x the latency of one round. jacb_eigen(8) spends ~3600 cycles per round: a row phase and a column
-// phase through LDS with a barrier after each, every wave recomputing angles it then broadcasts. Here a round is
-//   read pivots + operands (all LDS reads of the round issued up front) -> angle -> rotate 2x2 blocks in registers ->
-//   write -> barrier
-// built on three observations:
-//  * With ALL 32 angles of a round known, G' = R G R^T can be formed block-wise: the 2x2 block (row pair i, column pair j)
-//    of G' depends only on the same block of G and on the angles of i and j. No separate row and column phase.
+// ---- cross-only rotation rounds: one barrier per round, a dedicated pivot wave ----------------------------------------------
+// The 32 rounds of a cross-only visit are a dependent chain (the angles of round r+1 need the Gram matrix after round r), so the
+// visit costs 32 x the latency of one round. jacb_eigen(8) below spend ~3600 cycles per round: a row phase and a column phase
+// through LDS with a barrier after each, every wave recomputing angles it then broadcasts. Three observations remove most of it:
+//  * With ALL 32 angles of a round known, G' = R G R^T can be formed block-wise: the 2x2 block (row pair i, column pair j) of G'
+//    depends only on the same block of G and on the angles of i and j. No separate row and column phase.
 //  * Thread (row pair i, column pairs j) always owns the same entries of the A quadrant (rows and columns of block I keep their
-//    place): they stay in registers. C = G[I][J] and B = G[J][J] are double-buffered in LDS (read buffer r&1, write the other), so
-//    the reads and writes of a round need no barrier between them. The C^T quadrant is never stored (symmetry).
-//  * The accumulated transform Q only consumes angles: its update for round r is issued in round r+1, inside the latency of that
-//    round's angle chain. Rows of Q that belong to block I stay in registers, rows of block J pass through LDS.
-// Every wave computes all 32 angles itself (lane l: pair l & 31): 4 waves = 4 SIMDs, nothing is broadcast through LDS except the
-// column-pair angles (ds_bpermute). Angle formulas: c^2 = (1 + |d|/root)/2, s = g/(root*c), t = s/c, tau = s/(1+c) with
-// d = b - a, root = sqrt(d^2 + 4 g^2): two rsqrt chains and one rcp chain, no IEEE division.
-template <int NWV>                        // waves per workgroup: 4 or 8 (2 per SIMD: a lone wave only issues every other slot)
-__global__ __launch_bounds__(64 * NWV) void jacb_eigen_x(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
-                                                     JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
-                                                     double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                     unsigned long long* __restrict__ offmax, int max_inner, int dbg) {
-  constexpr int T = 64 * NWV, NB = 16 / NWV, NQ = 32 / NWV, KL = (PB * PB / 2) / T;
-  constexpr int LD = BB + 1;
-  __shared__ double sC[2][BB][LD];        // C(x, y) = G[x][32 + y]
-  __shared__ double sB[2][BB][LD];        // B(x, y) = G[32 + x][32 + y] (both triangles)
-  __shared__ double sD[2][BB];            // diagonal of the A quadrant
-  __shared__ double stage[PB][PB + 1];    // the summed Gram matrix on entry; afterwards its first 32 rows hold QJ (rows of Q of block J)
-  __shared__ double sRd[PB];              // 1 / diagonal (pre-check)
-  double (*QJ)[PB + 1] = stage;
-  const int pairIdx = blockIdx.x, mat = blockIdx.y;
-  if (st[mat].done) return;
-  int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
-  if (J >= nblk) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  {
-    // sum of the column chunks' partial Gram matrices, chunk order fixed; 16-byte loads, all of a chunk group in flight at once
-    const d2* Gp = reinterpret_cast<const d2*>(Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB));
-    d2 acc[KL];
-#pragma unroll
-    for (int k = 0; k < KL; k++) acc[k] = d2{0.0, 0.0};
-    for (int ch0 = 0; ch0 < nchunks; ch0 += 4) {
-      d2 v[4][KL];
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int k = 0; k < KL; k++)
-          v[c][k] = (ch0 + c < nchunks) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + T * k] : d2{0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int k = 0; k < KL; k++) acc[k] += v[c][k];
-    }
-#pragma unroll
-    for (int k = 0; k < KL; k++) {
-      const int e = 2 * (t + T * k);
-      stage[e / PB][e % PB] = acc[k].x;
-      stage[e / PB][e % PB + 1] = acc[k].y;
-    }
-  }
-  __syncthreads();
-  if (dbg == 1) return;
-  const double fl = floor2[mat];
-  // one pass over the off-diagonal: the largest cos^2 between two rows of the pair as they are NOW (the off-norm that the
-  // driver reports is the maximum over the visits of the last sweep), and whether any pair needs a rotation at all
-  if (t < PB) { const double dd = stage[t][t]; sRd[t] = dd > fl ? __builtin_amdgcn_rcp(dd) : 0.0; }   // 0: row at the noise floor
-  __syncthreads();
-  {
-    double rel = 0.0;
-    for (int e = t; e < PB * PB; e += T) {
-      const int x = e / PB, y = e % PB;
-      const double g = stage[x][y];
-      if (x < y) rel = fmax(rel, g * g * sRd[x] * sRd[y]);           // cos^2 (to the accuracy of v_rcp_f64: used for the decision
-    }                                                                //  with a 2^-20 margin, the rounds apply the exact criterion)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off));
-    if (lane == 0 && rel > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
-    const int need = __syncthreads_or(rel > tol2 * (1.0 - 0x1p-20));
-    if (!need || dbg == 2) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
-  }
-  const int i = lane & 31, h = lane >> 5;
-  const int jb = NB * (2 * wave + h);     // this thread's column pairs jb .. jb+NB-1
-  const int cb = NQ * (2 * wave + h);     // and its NQ columns of Q
-  double Areg[NB], Qp[NQ];
-#pragma unroll
-  for (int m = 0; m < NB; m++) Areg[m] = stage[i][jb + m];
-#pragma unroll
-  for (int m = 0; m < NQ; m++) Qp[m] = (cb + m == i) ? 1.0 : 0.0;
-  for (int e = t; e < BB * BB; e += T) {
-    const int x = e / BB, y = e % BB;
-    sC[0][x][y] = stage[x][BB + y];
-    sB[0][x][y] = stage[BB + x][BB + y];
-  }
-  if (t < BB) sD[0][t] = stage[t][t];
-  __syncthreads();                        // everybody is done with `stage`
-  for (int e = t; e < BB * PB; e += T) QJ[e / PB][e % PB] = (e % PB == BB + e / PB) ? 1.0 : 0.0;
-  __syncthreads();
-
-  unsigned total = 0, rot = 0;
-  double ps = 0.0, ptau = 0.0;            // angle of the previous round (pending update of Q)
-  int pip = 0;
-  const int nrounds = dbg == 3 ? 0 : BB * (max_inner < 1 ? 1 : max_inner);
-  for (int r = 0; r < nrounds; r++) {
-    const int cur = r & 1, nxt = cur ^ 1;
-    const int ip = (i + r) & (BB - 1);    // row pair i = rows (i, 32 + ip)
-    // ---- every LDS read of the round ----
-    const double a = sD[cur][i], b = sB[cur][ip][ip], g = sC[cur][i][ip];
-    double xpq[NB], xqp[NB], xqq[NB];
-    int jp[NB];
-#pragma unroll
-    for (int m = 0; m < NB; m++) {
-      jp[m] = (jb + m + r) & (BB - 1);
-      xpq[m] = sC[cur][i][jp[m]];
-      xqp[m] = sC[cur][jb + m][ip];
-      xqq[m] = sB[cur][ip][jp[m]];
-    }
-    double uq[NQ];
-#pragma unroll
-    for (int m = 0; m < NQ; m++) uq[m] = QJ[pip][cb + m];
-    // ---- angle of pair i (the same in every wave) ----
-    const bool go = (a > fl) && (b > fl) && (g * g > tol2 * a * b);
-    const double d = b - a, hh = g + g, rr = fma(d, d, hh * hh);
-    const double rs = fast_rsqrt(rr);                       // 1 / root
-    const double x = fma(0.5 * fabs(d), rs, 0.5);           // c^2 in [1/2, 1]
-    const double ric = fast_rsqrt(x);                       // 1 / c
-    const double c = x * ric;
-    const double sabs = fabs(g) * rs * ric;                 // |s| = |g| / (root c)
-    double s = ((d < 0.0) != (g < 0.0)) ? -sabs : sabs;
-    double tau = s * fast_rcp(1.0 + c);
-    if (!go) { s = 0.0; tau = 0.0; }
-    rot += (unsigned)__popc((unsigned)__ballot(go));        // lanes 0..31 = the 32 pairs of the round
-    // ---- pending update of Q (round r-1): only needs the old angle, fills the latency of the chain above ----
-#pragma unroll
-    for (int m = 0; m < NQ; m++) {
-      const double up = Qp[m];
-      Qp[m] = up - ps * (uq[m] + ptau * up);
-      QJ[pip][cb + m] = uq[m] + ps * (up - ptau * uq[m]);
-    }
-    ps = s; ptau = tau; pip = ip;
-    // ---- the 2x2 blocks (row pair i, column pair jb+m): left rotation with (s, tau), right with the column pair's.
-    // The pivot block (jb+m == i) goes through the same formulas: its off-diagonal comes out as the rounding residual of the
-    // annihilation (not an exact 0), which keeps G consistent with the accumulated Q. ----
-    double sjv[NB], tjv[NB];
-#pragma unroll
-    for (int m = 0; m < NB; m++) { sjv[m] = __shfl(s, jb + m); tjv[m] = __shfl(tau, jb + m); }
-#pragma unroll
-    for (int m = 0; m < NB; m++) {
-      const double sj = sjv[m], tj = tjv[m];
-      const double xpp = Areg[m];
-      const double ypp = xpp - s * (xqp[m] + tau * xpp), yqp = xqp[m] + s * (xpp - tau * xqp[m]);
-      const double ypq = xpq[m] - s * (xqq[m] + tau * xpq[m]), yqq = xqq[m] + s * (xpq[m] - tau * xqq[m]);
-      const double zpp = ypp - sj * (ypq + tj * ypp);
-      const double zpq = ypq + sj * (ypp - tj * ypq);
-      const double zqq = yqq + sj * (yqp - tj * yqq);
-      Areg[m] = zpp;
-      if (jb + m == i) sD[nxt][i] = zpp;
-      sC[nxt][i][jp[m]] = zpq;
-      sB[nxt][ip][jp[m]] = zqq;
-    }
-    __syncthreads();
-    if ((r & (BB - 1)) == BB - 1) {                         // end of an inner sweep (uniform: every wave counts all 32 pairs)
-      total += rot;
-      if (rot == 0) break;
-      rot = 0;
-    }
-  }
-  // the update of Q that is still pending
-#pragma unroll
-  for (int m = 0; m < NQ; m++) {
-    const double uqm = QJ[pip][cb + m], up = Qp[m];
-    Qp[m] = up - ps * (uqm + ptau * up);
-    QJ[pip][cb + m] = uqm + ps * (up - ptau * uqm);
-  }
-  __syncthreads();
-  if (total) {
-    double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
-#pragma unroll
-    for (int m = 0; m < NQ; m++) Qt[i * PB + cb + m] = Qp[m];
-    for (int e = t; e < BB * PB; e += T) Qt[BB * PB + e] = QJ[e / PB][e % PB];
-  }
-  if (t == 0) {
-    flags[mat * sF_mat + pairIdx] = total ? 1 : 0;
-    if (total) atomicAdd(&st[mat].rotations, total);
-  }
-}
-
-// ---- the same rounds with a dedicated pivot wave -------------------------------------------------------------------------
-// Measured (tools/lat_f64.hip): one wave issues one fp64 instruction per 8 cycles whether or not it depends on the previous
-// one, so a round costs every wave of jacb_eigen_x (angle chain ~50 + its blocks) x 8 cycles, ~1800 cycles in all. Here the
-// chain runs on ONE wave while eight others rotate: in interval k (between two barriers)
+//    place): they stay in registers. C = G[I][J] and B = G[J][J] are double-buffered in LDS (read one buffer, write the other), so
+//    the reads and writes of a round need no barrier between them. The C^T quadrant is never stored (symmetry). Rows of Q that
+//    belong to block I stay in registers too, rows of block J pass through LDS.
+//  * Measured (tools/lat_f64.hip): one wave issues one fp64 instruction per ~8 cycles whether or not it depends on the previous
+//    one, so what a round costs is the instruction count of its busiest wave. When every wave computes the angle chain (~50
+//    instructions) before its blocks, a round is ~1800 cycles (that version, jacb_eigen_x, took 36 us per visit against 54 us).
+// Here the chain runs on ONE wave while eight others rotate: in interval k (between two barriers)
 //   pivot wave : pivots of S_k from the near-diagonal entries of S_{k-1} and the angles of round k-1 (diagonal blocks in closed
 //                form, the off-diagonal pivot = one entry of block (i, i+1)), then the angle chain of round k -> LDS
 //   bulk waves : S_k = R_{k-1} S_{k-1} R_{k-1}^T and Q_k = R_{k-1} Q_{k-1}, angles of round k-1 read from LDS
 // Both read state k-1 and write state k (double-buffered), so one barrier per round remains and its critical path is
-// max(pivot, bulk) instead of their sum. The pivot wave keeps its own a, b, g in registers; they differ from the bulk's copies
-// by rounding only, and only the pivot wave's decide the angles that G and Q are BOTH rotated with, so G stays consistent
-// with the accumulated Q.
+// max(pivot, bulk) instead of their sum (~1300 cycles, 28 us per visit). The pivot wave keeps its own a, b, g in registers; they
+// differ from the bulk's copies by rounding only, and only the pivot wave's decide the angles that G and Q are BOTH rotated
+// with, so G stays consistent with the accumulated Q.
+// Angle formulas: c^2 = (1 + |d|/root)/2, s = g/(root*c), t = s/c, tau = s/(1+c) with d = b - a, root = sqrt(d^2 + 4 g^2): two
+// rsqrt chains and one rcp chain, no IEEE division.
 __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                                      JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
                                                      double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                     unsigned long long* __restrict__ offmax, int dbg, int precheck) {
+                                                     unsigned long long* __restrict__ offmax, int precheck) {
   constexpr int T = 576, TB = 512, NB = 2, NQ = 4;
   constexpr int LD = BB + 1;
   __shared__ double sC[2][BB][LD];        // C(x, y) = G[x][32 + y]
@@ -645,7 +358,6 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
     }
   }
   __syncthreads();
-  if (dbg == 1) return;
   const double fl = floor2[mat];
   // The pass over the off-diagonal (largest cos^2 of the pair as it is now = the off-norm the driver reports; converged pairs
   // leave here) costs 3.7 us of the visit. In the dense phase of the iteration every pair rotates anyway: the driver switches it
@@ -663,7 +375,7 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
     for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off));
     if (lane == 0 && rel > 0.0) atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
     const int need = __syncthreads_or(rel > tol2 * (1.0 - 0x1p-20));
-    if (!need || dbg == 2) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
+    if (!need) { if (t == 0) flags[mat * sF_mat + pairIdx] = 0; return; }
   }
   const int i = lane & 31, h = lane >> 5;
   const bool pivot = wave == 8;
@@ -687,7 +399,6 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
   if (t < BB) sA1[0][t] = stage[t][(t + 1) & (BB - 1)];
   __syncthreads();                        // everybody is done with `stage`
   for (int e = t; e < BB * PB; e += T) QJ[e / PB][e % PB] = (e % PB == BB + e / PB) ? 1.0 : 0.0;
-  if (dbg == 3) return;
   // interval k = 0 .. 32: the pivot wave produces the angles of round k (k < 32), the bulk applies round k-1 (k > 0)
   unsigned rot = 0;
   double ps = 0.0, ptau = 0.0, sn = 0.0, tn = 0.0;   // pivot wave: angle of round k-1 for pair i and for pair i+1
@@ -838,48 +549,29 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   double* Qt = Gpart + (size_t)batch * sG;
   int* flags = reinterpret_cast<int*>(Qt + (size_t)batch * sQ);
   const long sF = ((npairs + 1) / 2 + 1) * 2;          // ints per matrix
-  static const int max_inner = getenv("ND4HIP_JAC_INNER") ? atoi(getenv("ND4HIP_JAC_INNER")) : MAX_INNER_DEFAULT;
-  static const int cross = getenv("ND4HIP_JAC_CROSS") ? atoi(getenv("ND4HIP_JAC_CROSS")) : 1;
   for (int step = 0; step < nblk2 - 1; step++) {
-    static const int fuse_env = getenv("ND4HIP_JAC_FUSE") ? atoi(getenv("ND4HIP_JAC_FUSE")) : -1;
+    // step 0 of a sweep rotates all pairs of the 64 rows (the pairs inside a block are visited there, once per sweep); the later
+    // steps only the 32 x 32 pairs across the two blocks
+    const bool cross_only = step > 0;
     // fused Gram+eigen pays when the (pair, matrix) workgroups alone fill the chip about once or twice; with many
     // more of them the separate, fully parallel Gram launch hides its load latency better (measured at N = 512:
     // batch 64: 83 -> 52 ms fused; batch 128: 94 -> 102; batch 1024: 738 -> 790)
-    const bool fused = fuse_env >= 0 ? fuse_env != 0 : (N <= 1024 && batch * npairs >= 128 && batch * npairs <= 768);
+    const bool fused = N <= 1024 && batch * npairs >= 128 && batch * npairs <= 768;
     if (fused) {
-      hipLaunchKernelGGL(jacb_eigen<true>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
-                         W, N, sM, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
-                         (cross && step > 0) ? 1 : 0);
+      hipLaunchKernelGGL((jacb_eigen<true, 8>), dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
+                         W, N, sM, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, cross_only ? 1 : 0);
     } else {
       hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                          W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
-      static const int xdbg = getenv("ND4HIP_JAC_XDBG") ? atoi(getenv("ND4HIP_JAC_XDBG")) : 0;   // timing experiments only
-      static const int xk = getenv("ND4HIP_JAC_XKERNEL") ? atoi(getenv("ND4HIP_JAC_XKERNEL")) : 9;
-      if (xk == 9 && cross && step > 0 && max_inner == 1) {
+      if (cross_only) {
         hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)npairs, (unsigned)batch), dim3(576), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, xdbg, dense_phase ? 0 : 1);
-      } else if (xk == 4 && cross && step > 0) {
-        hipLaunchKernelGGL(jacb_eigen_x<4>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner, xdbg);
-      } else if (xk && cross && step > 0) {
-        hipLaunchKernelGGL(jacb_eigen_x<8>, dim3((unsigned)npairs, (unsigned)batch), dim3(512), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner, xdbg);
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1);
+      } else if ((long)batch * npairs <= 256) {            // few workgroups: latency matters, 16 waves hide more of it
+        hipLaunchKernelGGL((jacb_eigen<false, 2>), dim3((unsigned)npairs, (unsigned)batch), dim3(1024), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, 0);
       } else {
-      // ND4HIP_JAC_EIGEN8 = 0 (4 waves always) | 8 | 16; default: 16 waves when there are few workgroups
-      static const int e8 = getenv("ND4HIP_JAC_EIGEN8") ? atoi(getenv("ND4HIP_JAC_EIGEN8")) : -1;
-      const bool eight = e8 >= 0 ? e8 != 0 : ((long)batch * npairs <= 256);     // few workgroups: latency, not throughput, matters
-      if (eight && e8 != 8)
-        hipLaunchKernelGGL(jacb_eigen8<2>, dim3((unsigned)npairs, (unsigned)batch), dim3(1024), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
-                           (cross && step > 0) ? 1 : 0);
-      else if (eight)
-        hipLaunchKernelGGL(jacb_eigen8<4>, dim3((unsigned)npairs, (unsigned)batch), dim3(512), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
-                           (cross && step > 0) ? 1 : 0);
-      else
-      hipLaunchKernelGGL(jacb_eigen<false>, dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
-                         Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, max_inner,
-                         (cross && step > 0) ? 1 : 0);
+        hipLaunchKernelGGL((jacb_eigen<false, 8>), dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, 0);
       }
     }
     hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
