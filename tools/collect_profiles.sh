@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box: bash tools/collect_profiles.sh <outdir under gpurun_out>
+# kernel-trace/--stats runs and --pmc runs are separate invocations (the pool refuses them combined with other trace domains),
+# the program comes directly after `--`.
+set -u
+out=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $out
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+ks() { rocprofv3 --kernel-trace --stats --output-format csv -d $out/$1 -o p -- "${@:2}" > $out/$1.stdout 2> $out/$1.stderr; cp $out/$1/p_kernel_stats.csv $out/$1_kernel_stats.csv 2>/dev/null; echo "done $1"; }
+pmc() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $out/$1 -o p -- "${@:3}" > /dev/null 2>&1; echo "done pmc $1"; }
+ks bench_matmul4096 python3 $R/bench.py --steps 20 --warmup 3 --no-ops --no-cpu-baseline
+ks bench_default python3 $R/bench.py
+ks svd2048 python3 $R/tools/prof_ops.py svd
+ks lu_qr_chol_2048 python3 $R/tools/prof_ops.py lu qr chol
+ks svd_batch256x512 python3 $R/tools/prof_batch.py 256
+pmc gemm_fetch FETCH_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
+pmc gemm_write WRITE_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
+pmc gemm_busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
+pmc svd_fetch FETCH_SIZE python3 $R/tools/prof_ops.py svd --reps 1
+pmc svd_write WRITE_SIZE python3 $R/tools/prof_ops.py svd --reps 1
+ls $out
