@@ -187,19 +187,21 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
 
 def qr_panel(h, dev, M=2048, b=16, batch=256):
     """One panel factorisation kernel (Householder geqr2 + larft of b = 16 columns) on its own: a single 2048-row panel (one
-    workgroup: a latency chain) and 256 of them in one launch (one workgroup per matrix: where an HBM fraction is meaningful)."""
+    workgroup: a latency chain), 256 of them in one launch (one workgroup per matrix and per CU: the register tile of 4 rows x 16
+    columns per thread admits one workgroup per CU, so larger batches run at the same rate), and 2048 panels of 512 rows (1 row per
+    thread: three workgroups per CU)."""
     import ctypes
     from nd4js_amd import _lib
-    res = {"rows": M, "cols": b, "algorithmic_bytes_per_panel": 16 * M * b}
-    for name, nb in (("single", 1), ("batched", batch)):
-        A = dev.fill_uniform(21, (nb, M, b))
+    res = {"cols": b, "algorithmic_bytes_per_panel_row": 16 * b}
+    for name, rows, nb in (("single", M, 1), ("batched", M, batch), ("batched_512rows", 512, 2048)):
+        A = dev.fill_uniform(21, (nb, rows, b))
         V = torch.empty_like(A)
         T = torch.empty((nb, b, b), dtype=torch.float64, device="cuda")
         W = A.clone()
 
         def go():
             W.copy_(A)
-            _lib.check(h.lib.nd4hip_dgeqr2_panel_batched_dev(h.ptr, nb, M, b, ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(V.data_ptr()),
+            _lib.check(h.lib.nd4hip_dgeqr2_panel_batched_dev(h.ptr, nb, rows, b, ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(V.data_ptr()),
                                                              ctypes.c_void_p(T.data_ptr())))
 
         def only_copy():
@@ -207,6 +209,7 @@ def qr_panel(h, dev, M=2048, b=16, batch=256):
         ms_all = _median_ms(go, h)[0]
         ms_copy = _median_ms(only_copy, h)[0]
         us = max(ms_all - ms_copy, 1e-6) * 1e3
-        byts = 16.0 * M * b * nb
-        res[name] = {"panels": nb, "us": round(us, 2), "bytes": byts, "GBps": round(byts / us / 1e3, 1), "frac_hbm_peak": round(byts / us / 1e3 / PEAK_HBM_GBS, 4)}
+        byts = 16.0 * rows * b * nb
+        res[name] = {"panels": nb, "rows": rows, "us": round(us, 2), "bytes": byts, "GBps": round(byts / us / 1e3, 1),
+                     "frac_hbm_peak": round(byts / us / 1e3 / PEAK_HBM_GBS, 4)}
     return res
