@@ -147,6 +147,81 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   for (int e = threadIdx.x; e < PB * PB; e += 256) G[e] = s_g[e / PB][e % PB];
 }
 
+// ---- Gram partials, second form: tiles per wave, fragments through LDS -------------------------------------------------------
+// jacb_gram gives every wave its own columns and ALL ten tiles: each wave then loads four 16-row fragments straight from global
+// memory in MFMA layout (16 rows x 64 B per instruction) and the four waves' accumulators meet in a 4-phase LDS reduction.
+// Here the 64 x 256 chunk is staged through LDS in four sub-chunks of 64 columns (coalesced: 32 lanes read one 512-B row segment),
+// double-buffered, and each wave owns 2-3 of the ten tiles over ALL columns: no cross-wave reduction, every wave stores its
+// tiles itself. LDS image [64][66]: lane (fx, fk) of a fragment read hits bank (4 fx + 2 fk) mod 64 -> conflict-free b64 reads.
+template <int NT>
+__device__ __forceinline__ void gram2_tiles(d4 (&acc)[3], const double (*st)[PB + 2], const int (&ti)[3], const int (&tj)[3], int fx, int fk) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ks++) {
+    double f[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) f[q] = st[q * 16 + fx][ks * 4 + fk];
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ti[n]], f[tj[n]], acc[n], 0, 0, 0);
+  }
+}
+__global__ __launch_bounds__(256) void jacb_gram2(const double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
+                                                   const JacState* __restrict__ st, double* __restrict__ Gpart, int nchunks, long sG_mat) {
+  __shared__ double s_x[2][PB][PB + 2];
+  const int pairIdx = blockIdx.x, chunk = blockIdx.y, mat = blockIdx.z;
+  if (st[mat].done) return;
+  int I, J;
+  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  if (J >= nblk) return;
+  const double* W = Wm + mat * sM;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int fx = lane & 15, fk = lane >> 4;
+  // staging: d2 number q = t + 256 k of a 64 x 64 sub-chunk: row q >> 5, columns 2 (q & 31)
+  const double* src[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) src[k] = W + pair_row((t >> 5) + 8 * k, I, J) * N + chunk * CH + 2 * (t & 31);
+  const int nsub = (N - chunk * CH >= CH) ? CH / 64 : (N - chunk * CH) / 64;      // N % 64 == 0, wave-uniform
+  // Measured with parts of the kernel switched off: the load stream alone 7 us (4.8 TB/s), + MFMAs 11 us (10 tiles x 64 k-steps x
+  // 64 cycles over 4 SIMDs = 4.8 us per CU, only partly in the shadow of the loads), + the stores 13 us. One sub-chunk ahead is the
+  // best prefetch distance: with all four sub-chunks requested up front (4 LDS buffers) the kernel takes 14.2 us.
+  d2 v[8];
+  auto load = [&](int sub) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = *reinterpret_cast<const d2*>(src[k] + sub * 64);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) *reinterpret_cast<d2*>(&s_x[buf][(t >> 5) + 8 * k][2 * (t & 31)]) = v[k];
+  };
+  d4 acc[3] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+  if (nsub > 0) { load(0); stash(0); }
+  __syncthreads();
+  for (int sub = 0; sub < nsub; sub++) {
+    if (sub + 1 < nsub) load(sub + 1);
+    const double (*sx)[PB + 2] = s_x[sub & 1];
+    // tiles (i, j), i <= j, of the 4 x 4 tile grid: 3, 3, 2, 2 per wave
+    if (wave == 0)      { const int ti[3] = {0, 0, 0}, tj[3] = {0, 1, 2}; gram2_tiles<3>(acc, sx, ti, tj, fx, fk); }
+    else if (wave == 1) { const int ti[3] = {0, 1, 1}, tj[3] = {3, 1, 2}; gram2_tiles<3>(acc, sx, ti, tj, fx, fk); }
+    else if (wave == 2) { const int ti[3] = {1, 2, 2}, tj[3] = {3, 2, 2}; gram2_tiles<2>(acc, sx, ti, tj, fx, fk); }
+    else                { const int ti[3] = {2, 3, 3}, tj[3] = {3, 3, 3}; gram2_tiles<2>(acc, sx, ti, tj, fx, fk); }
+    if (sub + 1 < nsub) stash((sub + 1) & 1);
+    __syncthreads();
+  }
+  // Only the ten tiles with i <= j are stored (the consumers mirror after summing the chunks): the mirrored stores were
+  // 8-byte writes 512 B apart, 2 us of the kernel.
+  const int TI[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 2}, {2, 3, 3}};
+  const int TJ[4][3] = {{0, 1, 2}, {3, 1, 2}, {3, 2, 2}, {3, 3, 3}};
+  double* G = Gpart + mat * sG_mat + ((long)pairIdx * nchunks + chunk) * (PB * PB);
+  const int ntiles = wave < 2 ? 3 : 2;
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    if (n < ntiles) {
+      const int i = TI[wave][n], j = TJ[wave][n];
+#pragma unroll
+      for (int r = 0; r < 4; r++) G[(i * 16 + fk + 4 * r) * PB + j * 16 + fx] = acc[n][r];
+    }
+  }
+}
+
 // Two-phase rotation rounds (row phase, barrier, column phase, barrier) on the 64 x 64 Gram matrix in LDS: the full sweep of
 // step 0 and the mid-size batches. PW = pairs of a round per wave: 8 -> 4 waves (throughput: many workgroups per CU), 2 -> 16
 // waves (2048^2: 115.7 ms with 4 waves, 98.1 with 8, 95.0 with 16 when this kernel ran every step).
@@ -188,10 +263,13 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen(const double* __restrict
   } else {
     const double* Gp = Gpart + mat * sG_mat + (long)pairIdx * nchunks * (PB * PB);
     for (int e = t; e < PB * PB; e += 2048 / PW) {
+      const int r = e / PB, c = e % PB;
+      Q[r][c] = (r == c) ? 1.0 : 0.0;
+      if ((r >> 4) > (c >> 4)) continue;                     // the partials hold the ten 16 x 16 tiles on and above the diagonal
       double s = 0.0;
       for (int ch = 0; ch < nchunks; ch++) s += Gp[(long)ch * (PB * PB) + e];
-      G[e / PB][e % PB] = s;
-      Q[e / PB][e % PB] = (e / PB == e % PB) ? 1.0 : 0.0;
+      G[r][c] = s;
+      if ((r >> 4) != (c >> 4)) G[c][r] = s;
     }
   }
   __syncthreads();
@@ -343,8 +421,10 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
 #pragma unroll
       for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int k = 0; k < KL; k++)
-          v[c][k] = (ch0 + c < nchunks) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + TB * k] : d2{0.0, 0.0};
+        for (int k = 0; k < KL; k++) {
+          const int e = 2 * (t + TB * k);                    // the partials hold the ten 16 x 16 tiles on and above the diagonal
+          v[c][k] = (ch0 + c < nchunks && ((e / PB) >> 4) <= ((e % PB) >> 4)) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + TB * k] : d2{0.0, 0.0};
+        }
 #pragma unroll
       for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -352,9 +432,12 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
     }
 #pragma unroll
     for (int k = 0; k < KL; k++) {
-      const int e = 2 * (t + TB * k);
-      stage[e / PB][e % PB] = acc[k].x;
-      stage[e / PB][e % PB + 1] = acc[k].y;
+      const int e = 2 * (t + TB * k), r = e / PB, c = e % PB;
+      if ((r >> 4) <= (c >> 4)) {
+        stage[r][c] = acc[k].x;
+        stage[r][c + 1] = acc[k].y;
+        if ((r >> 4) != (c >> 4)) { stage[c][r] = acc[k].x; stage[c + 1][r] = acc[k].y; }
+      }
     }
   }
   __syncthreads();
@@ -561,8 +644,13 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
       hipLaunchKernelGGL((jacb_eigen<true, 8>), dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
                          W, N, sM, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, cross_only ? 1 : 0);
     } else {
-      hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
-                         W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+      static const bool gram1 = getenv("ND4HIP_JAC_GRAM1") != nullptr;             // A/B switch: the first form of the Gram kernel
+      if (gram1)
+        hipLaunchKernelGGL(jacb_gram, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
+                           W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+      else
+        hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
+                           W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
       if (cross_only) {
         hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)npairs, (unsigned)batch), dim3(576), 0, h->stream,
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1);
