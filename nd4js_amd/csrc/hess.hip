@@ -11,6 +11,7 @@
 // (v_k = 0 for k >= i, so the formulas hold for every column). Bound: HBM — 2 reads + 1 write of the active part of H
 // and of U per step; four launches per step (vector, read pass, partial reduction, update pass).
 #include "nd4hip_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -192,6 +193,198 @@ __global__ __launch_bounds__(256) void hess_pass_b(double* __restrict__ Hm, doub
   for (int j = r0; j < r0 + HR && j < nrows; j++) H[(long)j * N + k] -= y[j] * vk + v[j] * wk;
 }
 
+// ================================================================ blocked form (one large matrix) ==========================
+// Within a block of NBH steps H is NOT modified: with the reflectors V, and W, Y collected as columns,
+//     H_k = H_0 - V W^T - Y V^T          (each step: H' = H - v w^T - y v^T with y = H v, w = H^T v - (v^T y) v)
+// so a step needs ONE read pass over H_0 (y = H_0 v, x = H_0^T v) plus corrections with the N x k arrays,
+//     y -= V (W^T v) + Y (V^T v),   x -= W (V^T v) + V (Y^T v),   v^T y = v^T y_raw - sum_j (a_j b_j + b_j c_j)
+// (a = W^T v, b = V^T v, c = Y^T v), and the row the next reflector is built from is H_0[i,:] - V[i,:] W^T - Y[i,:] V^T.
+// The rank-2 read-modify-write pass of every step (hess_pass_b) becomes two GEMMs per block on the MFMA kernel.
+// V, W, Y are kept TRANSPOSED ([NBH][N], one reflector per row): every access below is contiguous across threads.
+constexpr int NBH = 32;
+constexpr int BR = 16;            // rows per workgroup of the read pass (32: fewer, fatter workgroups, 12.7 us instead of 9.4)
+constexpr int BC = 512;           // columns per workgroup of the read pass (256 threads x one 16-byte load per row)
+
+struct HessBlk {
+  double *Vt, *Wt, *Yt;          // [NBH][N], zero outside the steps done in this block
+  double *dots;                  // a, b, c: [3][NBH]
+  double *nrm;                   // [N]: the sub-diagonal entry of every finished row
+  double *ypart;                 // [N / BC][N]: per column chunk partials of y
+  double *vyp;                   // [row groups x column chunks]: partials of v^T y_raw
+  int* skipv;                    // [N]: step i skipped (row already in Hessenberg form)
+  double* vrows;                 // [nstore][N]: all reflectors as rows, in processing order (transposed into ws.vstore at the end)
+};
+
+// step i = k-th of its block: current row i (columns < i), its Householder vector (hessenberg.js:43-56). One workgroup.
+__global__ __launch_bounds__(512) void hessb_vec(const double* __restrict__ H, int N, int i, int k, HessWs ws, HessBlk bk) {
+  constexpr int T = 512;
+  extern __shared__ double s_row[];                   // [N]
+  __shared__ double s_red[2][T / 64];
+  __shared__ double s_vi[NBH], s_yi[NBH];
+  const int t = threadIdx.x, ii = i - 1;
+  if (t < NBH) { s_vi[t] = (t < k) ? bk.Vt[(long)t * N + i] : 0.0; s_yi[t] = (t < k) ? bk.Yt[(long)t * N + i] : 0.0; }
+  __syncthreads();
+  double m1 = 0.0;                                     // max |row[j]|, j < i-1
+  for (int c = t; c < i; c += T) {
+    double x = H[(long)i * N + c];
+    // 8 steps at a time, all 16 loads of a group in flight (rows >= k of Wt, Vt are zero: the tail group needs no guard)
+    for (int j0 = 0; j0 < k; j0 += 8) {
+      double wv[8], vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { wv[u] = bk.Wt[(long)(j0 + u) * N + c]; vv[u] = bk.Vt[(long)(j0 + u) * N + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) x -= s_vi[j0 + u] * wv[u] + s_yi[j0 + u] * vv[u];
+    }
+    s_row[c] = x;
+    if (c < ii) m1 = fmax(m1, fabs(x));
+  }
+  for (int off = 32; off > 0; off >>= 1) m1 = fmax(m1, __shfl_xor(m1, off));
+  if ((t & 63) == 0) s_red[0][t >> 6] = m1;
+  __syncthreads();                                    // also publishes s_row
+  m1 = s_red[0][0];
+#pragma unroll
+  for (int w = 1; w < T / 64; w++) m1 = fmax(m1, s_red[0][w]);
+  double* v = ws.v;
+  double* vrow = bk.vrows + (long)(N - 1 - i) * N;    // reflector number N-1-i (processing order)
+  if (m1 == 0.0) {                                    // NORM.max === 0 -> continue (:46)
+    for (int j = t; j < N; j += T) v[j] = 0.0;
+    if (t == 0) { ws.skip[0] = 1; bk.skipv[i] = 1; }
+    return;
+  }
+  // ONE scaled sum of squares over the entries left of (i, i-1), S1 = sum (x_j / m1)^2; the two FrobeniusNorm results of
+  // hessenberg.js:47-50 follow from it: sum over j <= i-1 of (x_j / mx)^2 = S1 (m1/mx)^2 + (h_ii / mx)^2 (same scaling, so no
+  // over/underflow either; rounding-level difference to accumulating them entry by entry)
+  double S1 = 0.0;
+  for (int j = t; j < ii; j += T) { const double x = s_row[j] / m1; S1 += x * x; }
+  for (int off = 32; off > 0; off >>= 1) S1 += __shfl_xor(S1, off);
+  if ((t & 63) == 0) s_red[1][t >> 6] = S1;
+  __syncthreads();
+  S1 = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; w++) S1 += s_red[1][w];
+  const double hii0 = s_row[ii];
+  const double mx = fmax(m1, fabs(hii0));
+  const double q1 = m1 / mx, q0 = hii0 / mx;
+  const double ss = S1 * q1 * q1 + q0 * q0;
+  const double nrm = (isfinite(mx) ? sqrt(ss) * mx : mx) * (hii0 > 0 ? -1.0 : 1.0);        // :47
+  const double hii = hii0 - nrm;                                                            // :48
+  const double mx2 = fmax(m1, fabs(hii));
+  const double r1 = m1 / mx2, r0 = hii / mx2;
+  const double div = sqrt(S1 * r1 * r1 + r0 * r0);
+  const double scale = 1.4142135623730951 / div;
+  for (int j = t; j < N; j += T) {
+    double vj = 0.0;
+    if (j < i) vj = (j == ii ? hii : s_row[j]) / mx2 * scale;                                // :51-52
+    v[j] = vj;
+    vrow[j] = vj;
+    bk.Vt[(long)k * N + j] = vj;
+  }
+  if (t == 0) { ws.skip[0] = 0; bk.skipv[i] = 0; bk.nrm[i] = nrm; }
+}
+
+// The read pass over H_0[0:i, :]: workgroup (row group g, column chunk c) reads BR rows x BC columns with ONE 16-byte load per
+// thread and row, all in flight at once; x partial [g][columns] (a thread owns its two columns: no reduction), y partial
+// [c][rows] (wave reduction per row). The workgroups past the grid of the pass compute a = W^T v, b = V^T v, c = Y^T v.
+__global__ __launch_bounds__(256) void hessb_pass(const double* __restrict__ H, int N, int i, int k, int ngroups, int nchunks, HessWs ws, HessBlk bk) {
+  if (ws.skip[0]) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* v = ws.v;
+  if ((int)blockIdx.x >= ngroups * nchunks) {                     // ---- the 3 k dot products, one wave each
+    const int d = ((int)blockIdx.x - ngroups * nchunks) * 4 + wave;
+    if (d >= 3 * k) return;
+    const int which = d / k, j = d % k;
+    const double* M = (which == 0 ? bk.Wt : (which == 1 ? bk.Vt : bk.Yt)) + (long)j * N;
+    double s = 0.0;
+    for (int r = lane; r < i; r += 64) s += M[r] * v[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) bk.dots[which * NBH + j] = s;
+    return;
+  }
+  __shared__ double s_y[4][BR];
+  const int g = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int r0 = g * BR, c = ch * BC + 2 * t;
+  const bool incol = c < N;                                       // N is even here (N >= 512 and the loads are 16-byte)
+  const double2 vc = (incol && c < i) ? double2{v[c], (c + 1 < i) ? v[c + 1] : 0.0} : double2{0.0, 0.0};   // y only sums columns < i
+  double2 hrow[BR];
+#pragma unroll
+  for (int r = 0; r < BR; r++)
+    hrow[r] = (incol && r0 + r < i) ? *reinterpret_cast<const double2*>(H + (long)(r0 + r) * N + c) : double2{0.0, 0.0};
+  double2 x = double2{0.0, 0.0};
+  double yp[BR];
+#pragma unroll
+  for (int r = 0; r < BR; r++) {
+    const double vr = (r0 + r < i) ? v[r0 + r] : 0.0;
+    x.x += vr * hrow[r].x; x.y += vr * hrow[r].y;
+    yp[r] = hrow[r].x * vc.x + hrow[r].y * vc.y;
+  }
+  if (incol) *reinterpret_cast<double2*>(ws.xpart + (long)g * N + c) = x;
+#pragma unroll
+  for (int r = 0; r < BR; r++) {
+    double s = yp[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) s_y[wave][r] = s;
+  }
+  __syncthreads();
+  if (t < 64) {                                                   // wave 0: the y partials of the BR rows and their share of v^T y
+    double yv = 0.0;
+    if (t < BR && r0 + t < i) {
+      const double ys = (s_y[0][t] + s_y[1][t]) + (s_y[2][t] + s_y[3][t]);
+      bk.ypart[(long)ch * N + r0 + t] = ys;
+      yv = ys * v[r0 + t];
+    }
+    for (int off = 32; off > 0; off >>= 1) yv += __shfl_xor(yv, off);
+    if (t == 0) bk.vyp[blockIdx.x] = yv;
+  }
+}
+
+// y and w of step (i, k) from the partials of the pass and the corrections; rows k of Yt and Wt. 32 indices per workgroup,
+// 8 thread groups share the partial sums of an index (short chains, fixed order: deterministic).
+__global__ __launch_bounds__(256) void hessb_reduce(int N, int i, int k, int nchunks, HessWs ws, HessBlk bk) {
+  if (ws.skip[0]) return;
+  __shared__ double s_red[4];
+  __shared__ double s_a[NBH], s_b[NBH], s_c[NBH];
+  __shared__ double s_px[RG][RC], s_py[RG][RC];
+  const int t = threadIdx.x;
+  if (t < NBH) { s_a[t] = t < k ? bk.dots[t] : 0.0; s_b[t] = t < k ? bk.dots[NBH + t] : 0.0; s_c[t] = t < k ? bk.dots[2 * NBH + t] : 0.0; }
+  // v^T y_raw from the per-workgroup partials of the pass (fixed order: deterministic)
+  double part = 0.0;
+  for (int j = t; j < ((i + BR - 1) / BR) * nchunks; j += 256) part += bk.vyp[j];
+  double vy = block_sum(part, s_red);                                // (ends with a barrier: s_a, s_b, s_c are visible)
+  for (int j = 0; j < k; j++) vy -= s_a[j] * s_b[j] + s_b[j] * s_c[j];
+  const int cidx = t % RC, grp = t / RC;
+  const int e = blockIdx.x * RC + cidx;
+  const int P = (i + BR - 1) / BR;
+  double x = 0.0, y = 0.0;
+  if (e < N) {
+    for (int p = grp; p < P; p += RG) x += ws.xpart[(long)p * N + e];
+    // corrections: thread group grp takes the steps j = grp, grp + RG, ...
+    for (int j = grp; j < k; j += RG) {
+      const double wj = bk.Wt[(long)j * N + e], vj = bk.Vt[(long)j * N + e], yj = bk.Yt[(long)j * N + e];
+      x -= wj * s_b[j] + vj * s_c[j];
+      y -= vj * s_a[j] + yj * s_b[j];
+    }
+    if (e < i) for (int ch = grp; ch < nchunks; ch += RG) y += bk.ypart[(long)ch * N + e];
+  }
+  s_px[grp][cidx] = x; s_py[grp][cidx] = y;
+  __syncthreads();
+  if (grp == 0 && e < N) {
+    double xs = 0.0, ys = 0.0;
+#pragma unroll
+    for (int q = 0; q < RG; q++) { xs += s_px[q][cidx]; ys += s_py[q][cidx]; }
+    bk.Wt[(long)k * N + e] = xs - vy * ws.v[e];
+    bk.Yt[(long)k * N + e] = (e < i) ? ys : 0.0;
+  }
+}
+
+// rows finished in the block [ilo, ihi]: zeros left of the sub-diagonal, the norm on it (hessenberg.js:83-84)
+__global__ __launch_bounds__(256) void hessb_fix(double* __restrict__ H, int N, int ilo, int ihi, HessBlk bk) {
+  const int i = ilo + blockIdx.y;
+  if (i > ihi || bk.skipv[i]) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < i - 1) H[(long)i * N + c] = 0.0;
+  else if (c == i - 1) H[(long)i * N + c] = bk.nrm[i];
+}
+
 __global__ void hess_fill(double* __restrict__ x, int n, double val) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = val;
@@ -240,6 +433,39 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
     hipLaunchKernelGGL(hess_fill, dim3((unsigned)((nstore + 255) / 256)), dim3(256), 0, h->stream, ones, nstore, 1.0);
   }
   const int cchunks = (N + 255) / 256;
+  const bool blocked_path = wy && batch == 1 && N >= 512 && (N & 1) == 0 && (size_t)N * sizeof(double) <= 48 * 1024 && !getenv("ND4HIP_HESS_UNBLOCKED");
+  if (blocked_path) {
+    // ---- blocked: NBH steps per block, H untouched inside a block, two GEMMs per block ----
+    const int nchunks = (N + BC - 1) / BC;
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)3 * N * NBH + 3 * NBH + (size_t)N + (size_t)nchunks * N + (size_t)((N + BR - 1) / BR) * nchunks + (size_t)nstore * N) +
+                                sizeof(int) * (size_t)N + 64, &q));
+    HessBlk bk;
+    bk.Vt = static_cast<double*>(q); bk.Wt = bk.Vt + (size_t)N * NBH; bk.Yt = bk.Wt + (size_t)N * NBH;
+    bk.dots = bk.Yt + (size_t)N * NBH; bk.nrm = bk.dots + 3 * NBH; bk.ypart = bk.nrm + N; bk.vyp = bk.ypart + (size_t)nchunks * N;
+    bk.vrows = bk.vyp + (size_t)((N + BR - 1) / BR) * nchunks;
+    bk.skipv = reinterpret_cast<int*>(bk.vrows + (size_t)nstore * N);
+    ND4_HIP(hipMemsetAsync(bk.skipv, 0, sizeof(int) * (size_t)N, h->stream));
+    ND4_HIP(hipMemsetAsync(bk.vrows, 0, sizeof(double) * (size_t)nstore * N, h->stream));
+    for (int ihi = N - 1; ihi > 1; ihi -= NBH) {
+      const int ilo = ihi - NBH + 1 > 2 ? ihi - NBH + 1 : 2;
+      ND4_HIP(hipMemsetAsync(bk.Vt, 0, sizeof(double) * (size_t)3 * N * NBH, h->stream));
+      for (int i = ihi, k = 0; i >= ilo; i--, k++) {
+        const int ngroups = (i + BR - 1) / BR, ndot = (3 * k + 3) / 4;
+        hipLaunchKernelGGL(hessb_vec, dim3(1), dim3(512), (size_t)N * sizeof(double), h->stream, H, N, i, k, ws, bk);
+        hipLaunchKernelGGL(hessb_pass, dim3((unsigned)(ngroups * nchunks + ndot)), dim3(256), 0, h->stream, H, N, i, k, ngroups, nchunks, ws, bk);
+        hipLaunchKernelGGL(hessb_reduce, dim3((unsigned)((N + RC - 1) / RC)), dim3(256), 0, h->stream, N, i, k, nchunks, ws, bk);
+      }
+      ND4_HIP(hipGetLastError());
+      const int nk = ihi - ilo + 1;
+      // H[0:ihi, :] -= V W^T + Y V^T   (rows >= ihi: V and Y are zero there); V^T etc. are stored [NBH][N]: transA
+      ND4_TRY(nd4_gemm(h, true, false, ihi, N, nk, -1.0, bk.Vt, N, 0, bk.Wt, N, 0, 1.0, H, N, 0, 1));
+      ND4_TRY(nd4_gemm(h, true, false, ihi, N, nk, -1.0, bk.Yt, N, 0, bk.Vt, N, 0, 1.0, H, N, 0, 1));
+      hipLaunchKernelGGL(hessb_fix, dim3((unsigned)((N + 255) / 256), (unsigned)nk), dim3(256), 0, h->stream, H, N, ilo, ihi, bk);
+    }
+    ND4_HIP(hipGetLastError());
+    ND4_TRY(nd4_transpose(h, nstore, N, bk.vrows, N, ws.vstore, nstore, 1, 0, 0));     // reflectors as columns for nd4_wy_form
+  } else
   for (int i = N - 1; i > 1; i--) {
     hipLaunchKernelGGL(hess_vec, dim3((unsigned)batch), dim3(256), 0, h->stream, H, N, i, ws);
     const unsigned rg = (unsigned)((N - 1 + HR - 1) / HR);           // row groups: enough for U's N-1 rows (H uses i <= N-1)

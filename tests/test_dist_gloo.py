@@ -43,6 +43,11 @@ def _worker(rank, world, port, batch, n, out_dir):
         assert sv_all.shape == (batch, n) and U.shape == (hi - lo, n, n)
         assert health["max_sweeps"] >= 1 and not health["failed"]
         np.save(os.path.join(out_dir, "sv_rank%d.npy" % rank), sv_all.numpy())
+        # R3: U and V gathered whole on every rank (uneven blocks, padding trimmed)
+        Ua, _, Va, _ = svd_decomp_sharded(A, batch, compute=_cpu_compute, gather_uv=True)
+        assert Ua.shape == (batch, n, n) and Va.shape == (batch, n, n)
+        assert torch.equal(Ua[lo:hi], U) and torch.equal(Va[lo:hi], V)
+        np.save(os.path.join(out_dir, "u_rank%d.npy" % rank), Ua.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -59,6 +64,9 @@ def test_sharded_svd_world2_gloo(tmp_path):
     assert np.array_equal(sv0, sv1)               # every rank holds the whole gathered result
     ref = np.stack([oracle.svd_jac_2sided(rng.matrix(1000 + b, n, n))[1] for b in range(batch)])
     assert np.array_equal(sv0, ref)               # sharding changed nothing: bit-identical to the serial run
+    u0, u1 = np.load(tmp_path / "u_rank0.npy"), np.load(tmp_path / "u_rank1.npy")
+    assert np.array_equal(u0, u1)                 # R3: both ranks hold the same whole U
+    assert np.array_equal(u0[4], oracle.svd_jac_2sided(rng.matrix(1000 + 4, n, n))[0])
 
 
 def _failing_worker(rank, world, port, batch, n, out_dir):

@@ -1,6 +1,13 @@
-import sys
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace --stats -- python3 tools/prof_hess.py [N] [hess|bidiag]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nd4js_amd import dev
-A = dev.fill_uniform(7, (2048, 2048))
-dev.hessenberg_decomp(A); torch.cuda.synchronize()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+what = sys.argv[2] if len(sys.argv) > 2 else "hess"
+A = dev.fill_uniform(7, (N, N))
+for _ in range(2):
+    dev.hessenberg_decomp(A) if what == "hess" else dev.bidiag_decomp(A)
+torch.cuda.synchronize()
+print("done")
