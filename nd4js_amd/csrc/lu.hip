@@ -5,7 +5,7 @@
 //   lu_panel_* one workgroup per matrix factors rows [j0,N) x cols [j0,j0+nb): per column a
 //              wave-shuffle + LDS arg-max (ties -> lowest row, exactly the reference's strict '>' scan,
 //              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. lu_panel_row<R>: one thread per
-//              row, the R x 16 tile of each lane in registers (m <= 2048); lu_panel_row_wt<R,W,T>: the same on
+//              row, the R x 16 tile of each lane in registers (m <= 2048); lu_panel_row<R,W,1024>: the same on
 //              1024 threads with 8- / 4-column panels (m <= 4096 / 8192); lu_panel_global: 16 lanes
 //              per row / panel in global memory (anything taller).
 //   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61 swaps full
@@ -97,141 +97,18 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
   }
 }
 
-// ---- thread-per-row panel kernel: each thread keeps R whole panel rows (16 doubles each) in registers ----
-// Row r = j0 + t + 512*i (512 threads: 256 VGPRs per lane hold up to 6 rows x 16 columns). Per column: ONE true division and 15-k FMAs per row, no cross-lane traffic in
-// the update; the arg-max is a wave shuffle reduction + 16 LDS partials that every thread finishes itself
-// (no second barrier); the pivot row and the displaced row travel through LDS. The k-loop is fully
-// unrolled so that every register index is static. 2 barriers per column.
-template <int R>
-__global__ __launch_bounds__(512) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
-  __shared__ PivCand s_red[8];
-  __shared__ double s_u[NB], s_j[NB];
-  double* A = LU + blockIdx.x * strideM;
-  int32_t* ip = ipiv + (long)blockIdx.x * N;
-  const int t = threadIdx.x, wave = t >> 6;
-  double a[R][NB];
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + t + 512 * i;
-#pragma unroll
-    for (int c = 0; c < NB; c++) a[i][c] = 0.0;
-    if (r < N) {
-      const double* src = A + (long)r * N + j0;
-      if (nb == NB && (N & 1) == 0) {                    // 16-byte loads: each lane reads its own 128-B row segment
-#pragma unroll
-        for (int c = 0; c < NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
-      } else {
-#pragma unroll
-        for (int c = 0; c < NB; c++) if (c < nb) a[i][c] = src[c];
-      }
-    }
-  }
-  // The column loop is expanded at compile time (a generic lambda called with integral constants), not by the loop unroller:
-  // the DPP cross-lane moves are convergent operations, a loop that contains them is only unrolled late, after the pass that
-  // splits the register tile into scalars has run, and the tile would then live in scratch memory.
-  auto column = [&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    if (k < nb) {                                        // uniform
-      const int jc = j0 + k;
-      // ---- arg-max of |column k| over rows >= jc ----
-      PivCand cand{-2.0, 0x7fffffff};
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 512 * i;
-        PivCand o{pivot_mag(a[i][k], r, jc), r};
-        if (r < jc || r >= N) o.mag = -2.0;
-        cand = better(cand, o);
-      }
-      // wave arg-max on DPP (VALU speed; a ds_bpermute butterfly is six dependent LDS-crossbar round trips): the largest
-      // magnitude first, then the lowest row among the lanes that hold it (first maximum, lu.js:50-52)
-      const double wm = nd4dpp::wave_max(cand.mag);
-      const int wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
-      if ((t & 63) == 0) { s_red[wave].mag = wm; s_red[wave].idx = wi; }
-      __syncthreads();
-      // the 8 wave candidates: lane l reads candidate l & 7, three DPP steps leave the block result in every lane
-      const PivCand c8 = s_red[t & 7];
-      double bm = fmax(c8.mag, nd4dpp::xor1(c8.mag)); bm = fmax(bm, nd4dpp::xor2(bm)); bm = fmax(bm, nd4dpp::xor4(bm));
-      int bi = c8.mag == bm ? c8.idx : 0x7fffffff;
-      bi = min(bi, nd4dpp::xor1(bi)); bi = min(bi, nd4dpp::xor2(bi)); bi = min(bi, nd4dpp::xor4(bi));
-      const int piv = nopivot ? jc : bi;               // (kept in a VGPR: a scalar row index would turn the `i == pi` selects below
-                                                       //  into a dynamically indexed register tile, i.e. scratch memory)
-      if (t == 0) {
-        ip[jc] = piv;
-        }
-      // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
-      // (each row slot tests its own row number: a slot index derived from piv would let the optimiser turn the tile into a
-      //  dynamically indexed array, i.e. scratch memory)
-#pragma unroll
-      for (int i = 0; i < R; i++)
-        if (j0 + t + 512 * i == piv) {
-#pragma unroll
-          for (int c = 0; c < NB; c++) s_u[c] = a[i][c];
-        }
-      if (t == k) {
-#pragma unroll
-        for (int c = 0; c < NB; c++) s_j[c] = a[0][c];
-      }
-      __syncthreads();
-      if (piv != jc) {
-#pragma unroll
-        for (int i = 0; i < R; i++)
-          if (j0 + t + 512 * i == piv) {
-#pragma unroll
-            for (int c = 0; c < NB; c++) a[i][c] = s_j[c];
-          }
-        if (t == k) {
-#pragma unroll
-          for (int c = 0; c < NB; c++) a[0][c] = s_u[c];
-        }
-      }
-      // ---- eliminate below the pivot ----
-      const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
-      const double pk = u[k];
-      const double rk = (pk == 0.0 || pk != pk || __builtin_isinf(pk)) ? 1.0 / pk : nd4dpp::fast_rcp(pk);   // 0, Inf, NaN pivots: IEEE semantics
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 512 * i;
-        if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
-          // a / pivot (lu.js:68) as a * (1/pivot) with one residual correction: the quotient of a division that comes out
-          // exact (integer-valued and structured inputs, where later pivot TIES depend on it) is reproduced exactly, any other
-          // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division
-          const double q0 = a[i][k] * rk;
-          const double l = fma(fma(-q0, pk, a[i][k]), rk, q0);
-          a[i][k] = l;
-#pragma unroll
-          for (int c = k + 1; c < NB; c++) a[i][c] -= l * u[c];   // lu.js:71-72
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);                   // keep the unrolled columns from interleaving (VGPR pressure)
-  };
-#define ND4_COL(K) column(std::integral_constant<int, K>{});
-  ND4_COL(0) ND4_COL(1) ND4_COL(2) ND4_COL(3) ND4_COL(4) ND4_COL(5) ND4_COL(6) ND4_COL(7)
-  ND4_COL(8) ND4_COL(9) ND4_COL(10) ND4_COL(11) ND4_COL(12) ND4_COL(13) ND4_COL(14) ND4_COL(15)
-#undef ND4_COL
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + t + 512 * i;
-    if (r < N) {
-      double* dst = A + (long)r * N + j0;
-      if (nb == NB && (N & 1) == 0) {
-#pragma unroll
-        for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(dst + c) = double2{a[i][c], a[i][c + 1]};
-      } else {
-#pragma unroll
-        for (int c = 0; c < NB; c++) if (c < nb) dst[c] = a[i][c];
-      }
-    }
-  }
-}
-
-// The same kernel for taller panels: T = 1024 threads leave 128 VGPRs per lane, enough for R = 4 rows of W = 8 columns:
-// 2048 < m <= 4096 rows are factorised 8 columns at a time instead of falling back to the global-memory panel.
+// ---- thread-per-row panel kernel: each of T threads keeps R whole panel rows (W doubles each) in registers ----
+// Row r = j0 + t + T*i. <R, 16, 512>: m <= 2048 (R = 1, 2, 4). Taller panels keep the layout on 1024 threads (128 VGPRs per lane) by
+// narrowing the panel: <4, 8, 1024> up to 4096 rows (8-column panels), <8, 4, 1024> up to 8192 rows (4-column panels).
+// Per column: one reciprocal + a residual correction and W-1-k FMAs per row, no cross-lane traffic in the update; the arg-max is a DPP
+// wave reduction + T/64 LDS partials that every thread finishes itself (no second barrier); the pivot row and the displaced
+// row travel through LDS. The column loop is expanded at compile time, so every register index is static. 2 barriers per column.
 template <int R, int W, int T>
-__global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+__global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
                                                        int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
-  __shared__ PivCand s_red[T / 64];
+  constexpr int NWV = T / 64;
+  static_assert(NWV == 8 || NWV == 16, "8 or 16 waves");
+  __shared__ PivCand s_red[NWV];
   __shared__ double s_u[W], s_j[W];
   double* A = LU + blockIdx.x * strideM;
   int32_t* ip = ipiv + (long)blockIdx.x * N;
@@ -253,8 +130,11 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < W; k++) {
+  // The column loop is expanded at compile time (a generic lambda called with integral constants), not by the loop unroller:
+  // the DPP cross-lane moves are convergent operations, a loop that contains them is only unrolled late, after the pass that
+  // splits the register tile into scalars has run, and the tile would then live in scratch memory.
+  auto column = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     if (k < nb) {                                        // uniform
       const int jc = j0 + k;
       // ---- arg-max of |column k| over rows >= jc ----
@@ -266,46 +146,45 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
         if (r < jc || r >= N) o.mag = -2.0;
         cand = better(cand, o);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        PivCand o;
-        o.mag = __shfl_xor(cand.mag, off);
-        o.idx = __shfl_xor(cand.idx, off);
-        cand = better(cand, o);
-      }
-      if ((t & 63) == 0) s_red[wave] = cand;
+      // wave arg-max on DPP (VALU speed; a ds_bpermute butterfly is six dependent LDS-crossbar round trips): the largest
+      // magnitude first, then the lowest row among the lanes that hold it (first maximum, lu.js:50-52)
+      const double wm = nd4dpp::wave_max(cand.mag);
+      const int wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
+      if ((t & 63) == 0) { s_red[wave].mag = wm; s_red[wave].idx = wi; }
       __syncthreads();
-      PivCand best = s_red[0];
-#pragma unroll
-      for (int w = 1; w < T / 64; w++) best = better(best, s_red[w]);
-      const int piv = nopivot ? jc : best.idx;
+      // the wave candidates: lane l reads candidate l & (NWV - 1), log2(NWV) DPP steps leave the block result in every lane
+      const PivCand c8 = s_red[t & (NWV - 1)];
+      double bm = fmax(c8.mag, nd4dpp::xor1(c8.mag)); bm = fmax(bm, nd4dpp::xor2(bm)); bm = fmax(bm, nd4dpp::xor4(bm));
+      if constexpr (NWV == 16) bm = fmax(bm, nd4dpp::xor8(bm));
+      int bi = c8.mag == bm ? c8.idx : 0x7fffffff;
+      bi = min(bi, nd4dpp::xor1(bi)); bi = min(bi, nd4dpp::xor2(bi)); bi = min(bi, nd4dpp::xor4(bi));
+      if constexpr (NWV == 16) bi = min(bi, nd4dpp::xor8(bi));
+      const int piv = nopivot ? jc : bi;               // (kept in a VGPR: a scalar row index would turn the `i == pi` selects below
+                                                       //  into a dynamically indexed register tile, i.e. scratch memory)
       if (t == 0) {
         ip[jc] = piv;
         }
       // ---- publish the pivot row and the displaced row jc (owner: thread k, slot 0) ----
-      const int pt = (piv - j0) % T, pi = (piv - j0) / T;
-      if (t == pt) {
+      // (each row slot tests its own row number: a slot index derived from piv would let the optimiser turn the tile into a
+      //  dynamically indexed array, i.e. scratch memory)
 #pragma unroll
-        for (int i = 0; i < R; i++)
-          if (i == pi) {
+      for (int i = 0; i < R; i++)
+        if (j0 + t + T * i == piv) {
 #pragma unroll
-            for (int c = 0; c < W; c++) s_u[c] = a[i][c];
-          }
-      }
+          for (int c = 0; c < W; c++) s_u[c] = a[i][c];
+        }
       if (t == k) {
 #pragma unroll
         for (int c = 0; c < W; c++) s_j[c] = a[0][c];
       }
       __syncthreads();
       if (piv != jc) {
-        if (t == pt) {
 #pragma unroll
-          for (int i = 0; i < R; i++)
-            if (i == pi) {
+        for (int i = 0; i < R; i++)
+          if (j0 + t + T * i == piv) {
 #pragma unroll
-              for (int c = 0; c < W; c++) a[i][c] = s_j[c];
-            }
-        }
+            for (int c = 0; c < W; c++) a[i][c] = s_j[c];
+          }
         if (t == k) {
 #pragma unroll
           for (int c = 0; c < W; c++) a[0][c] = s_u[c];
@@ -313,11 +192,17 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
       }
       // ---- eliminate below the pivot ----
       const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
+      const double pk = u[k];
+      const double rk = (pk == 0.0 || pk != pk || __builtin_isinf(pk)) ? 1.0 / pk : nd4dpp::fast_rcp(pk);   // 0, Inf, NaN pivots: IEEE semantics
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + T * i;
         if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
-          const double l = a[i][k] / u[k];               // lu.js:68
+          // a / pivot (lu.js:68) as a * (1/pivot) with one residual correction: the quotient of a division that comes out
+          // exact (integer-valued and structured inputs, where later pivot TIES depend on it) is reproduced exactly, any other
+          // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division
+          const double q0 = a[i][k] * rk;
+          const double l = fma(fma(-q0, pk, a[i][k]), rk, q0);
           a[i][k] = l;
 #pragma unroll
           for (int c = k + 1; c < W; c++) a[i][c] -= l * u[c];   // lu.js:71-72
@@ -325,7 +210,12 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
       }
     }
     __builtin_amdgcn_sched_barrier(0);                   // keep the unrolled columns from interleaving (VGPR pressure)
-  }
+  };
+#define ND4_COL(K) column(std::integral_constant<int, K>{});
+  ND4_COL(0) ND4_COL(1) ND4_COL(2) ND4_COL(3)
+  if constexpr (W > 4) { ND4_COL(4) ND4_COL(5) ND4_COL(6) ND4_COL(7) }
+  if constexpr (W > 8) { ND4_COL(8) ND4_COL(9) ND4_COL(10) ND4_COL(11) ND4_COL(12) ND4_COL(13) ND4_COL(14) ND4_COL(15) }
+#undef ND4_COL
 #pragma unroll
   for (int i = 0; i < R; i++) {
     const int r = j0 + t + T * i;
@@ -341,6 +231,7 @@ __global__ __launch_bounds__(T) void lu_panel_row_wt(double* __restrict__ LU, in
     }
   }
 }
+
 
 // ---- apply the panel's row swaps to the columns outside the panel, and (fused) U12 = L11^-1 A12 for the columns to
 // its right: both are one-thread-per-column jobs over the same columns, and the 16 swapped-in pivot rows are exactly the
@@ -441,14 +332,14 @@ __global__ void lu_build_perm_global(int32_t* __restrict__ Pm, const int32_t* __
 
 template <int R>
 void launch_panel_row(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
-  hipLaunchKernelGGL((lu_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+  hipLaunchKernelGGL((lu_panel_row<R, NB, 512>), dim3(batch), dim3(512), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
 }
 
 }  // namespace
 
 template <int R, int W, int T>
 void launch_panel_row_wt(nd4hip_handle* h, double* LU, int N, long strideM, int j0, int nb, int32_t* P, int32_t* ipiv, int batch, int nopivot) {
-  hipLaunchKernelGGL((lu_panel_row_wt<R, W, T>), dim3(batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+  hipLaunchKernelGGL((lu_panel_row<R, W, T>), dim3(batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
 }
 
 static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double* A, double* LU, int32_t* P, int nopivot) {

@@ -372,17 +372,25 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   }
 }
 
-// ---- the same panel kernel for 2048 < m <= 4096 rows: 1024 threads leave 128 VGPRs per lane = R = 4 rows of EIGHT columns.
-// A 16-column panel slot is then factorised in parts (two 8-column halves here, four 4-column quarters in qr_panel_row4).
+// ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
+// 2048 < m <= 4096 rows: R = 4, W = 8; 4096 < m <= 8192 rows: R = 8, W = 4.
+// A 16-column panel slot is then factorised in parts (two 8-column halves / four 4-column quarters).
 // Every part writes ONLY its own triangular factor into the live T slot (zeros elsewhere), so that the ordinary
 // block-reflector machinery applies just this part's reflectors to the remaining columns of the slot, and also into a
 // side slot that collects the diagonal blocks; qr_t_assemble then builds the full 16 x 16 factor from them and V^T V.
-template <int R>
-__global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, int M, long ld, long strideW,
+template <int W> __device__ __forceinline__ double qr_xor_lanes(double v) {       // value of lane ^ W inside a row of 16 lanes
+  if constexpr (W == 1) return nd4dpp::xor1(v);
+  else if constexpr (W == 2) return nd4dpp::xor2(v);
+  else if constexpr (W == 4) return nd4dpp::xor4(v);
+  else return nd4dpp::xor8(v);
+}
+template <int R, int W8>
+__global__ __launch_bounds__(1024) void qr_panel_part(double* __restrict__ Wm, int M, long ld, long strideW,
                                                      double* __restrict__ Vall, long ldv, long strideV,
                                                      double* __restrict__ Tall, double* __restrict__ Tside, long strideT,
                                                      double* __restrict__ taus, long strideTau, int c0, int nb) {
-  constexpr int W8 = 8, NW = 16;                       // columns of this kernel, waves per workgroup
+  constexpr int NW = 16;                               // waves per workgroup (W8 = columns of this kernel)
+  static_assert(W8 == 8 || W8 == 4, "two halves or four quarters of a 16-column slot");
   __shared__ double s_red[NW];
   __shared__ double s_w[NW][W8];
   __shared__ double s_T[W8][W8 + 1];
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, i
   double* V = Vall + blockIdx.x * strideV;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-  const int mycol = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);                   // column this lane ends up with
+  const int mycol = W8 == 8 ? (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0) : (b0 ? 2 : 0) + (b1 ? 1 : 0);   // column this lane ends up with
 
   double a[R][W8];
 #pragma unroll
@@ -454,194 +462,34 @@ __global__ __launch_bounds__(1024) void qr_panel_row8(double* __restrict__ Wm, i
 #pragma unroll
         for (int c = 0; c < W8; c++) d[c] += vr[i] * a[i][c];
       }
-      // halving butterfly over the 8 lanes of a group (4 + 2 + 1 exchanges), then across the 8 groups of the wave
+      // halving butterfly over the W8 lanes of a group (W8/2 + ... + 1 exchanges), then across the groups of the wave
       double e4[4], e2[2], e1;
+      if constexpr (W8 == 8) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) { const double snd = b0 ? d[j] : d[j + 4], kp = b0 ? d[j + 4] : d[j]; e4[j] = kp + nd4dpp::xor1(snd); }
+        for (int j = 0; j < 4; j++) { const double snd = b0 ? d[j] : d[j + 4], kp = b0 ? d[j + 4] : d[j]; e4[j] = kp + nd4dpp::xor1(snd); }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2; j++) { const double snd = b1 ? e4[j] : e4[j + 2], kp = b1 ? e4[j + 2] : e4[j]; e2[j] = kp + nd4dpp::xor2(snd); }
-      { const double snd = b2 ? e2[0] : e2[1], kp = b2 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor4(snd); }
+        for (int j = 0; j < 4; j++) e4[j] = d[j];
+      }
+      {
+        const bool bb = W8 == 8 ? b1 : b0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) { const double snd = bb ? e4[j] : e4[j + 2], kp = bb ? e4[j + 2] : e4[j]; e2[j] = kp + qr_xor_lanes<W8 / 4>(snd); }
+      }
+      { const bool bb = W8 == 8 ? b2 : b1; const double snd = bb ? e2[0] : e2[1], kp = bb ? e2[1] : e2[0]; e1 = kp + qr_xor_lanes<W8 / 2>(snd); }
+      if constexpr (W8 == 4) e1 += nd4dpp::xor4(e1);
       e1 += nd4dpp::xor8(e1);
       e1 += __shfl_xor(e1, 16);
       e1 += __shfl_xor(e1, 32);
       if (lane < W8) s_w[wave][mycol] = e1;
       __syncthreads();
-      double tot = 0.0;                                   // lane -> column lane & 7
+      double tot = 0.0;                                   // lane -> column lane & (W8 - 1)
 #pragma unroll
-      for (int w = 0; w < NW; w++) tot += s_w[w][lane & 7];
-      double wv[W8];                                      // wave-uniform totals
-#define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
-      ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3) ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7)
-#undef ND4_RL
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 1024 * i;
-        const double tv = tau * vr[i];
-#pragma unroll
-        for (int c = k + 1; c < W8; c++) a[i][c] -= tv * wv[c];
-        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
-      }
-      if (t == 0) {
-#pragma unroll
-        for (int c = 0; c < W8; c++) if (c < k) s_Z[k][c] = wv[c];
-        s_tau[k] = tau;
-        taus[blockIdx.x * strideTau + j0 + k] = tau;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#define ND4_STEP(K) column_step(std::integral_constant<int, K>{});
-  ND4_STEP(0) ND4_STEP(1) ND4_STEP(2) ND4_STEP(3) ND4_STEP(4) ND4_STEP(5) ND4_STEP(6) ND4_STEP(7)
-#undef ND4_STEP
-  __syncthreads();
-  if (t < nb) {                                          // larft: row t of T depends only on row t
-    double row[W8];
-#pragma unroll
-    for (int k = 0; k < W8; k++) row[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < W8; k++) {
-      if (k == t) row[k] = s_tau[k];
-      else if (k > t && k < nb) {
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < W8; j++) if (j >= t && j < k) sum += row[j] * s_Z[k][j];
-        row[k] = -s_tau[k] * sum;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < W8; k++) s_T[t][k] = row[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int lr = t + 1024 * i, r = j0 + lr;
-    if (r < M) {
-      double* w = A + (long)r * ld + j0;
-      double* v = V + (long)r * ldv + j0;
-      double wv[W8], vv[W8];
-#pragma unroll
-      for (int c = 0; c < W8; c++) {
-        wv[c] = (lr <= c) ? a[i][c] : 0.0;                       // R part (upper triangle incl. diagonal)
-        vv[c] = (lr < c) ? 0.0 : ((lr == c) ? 1.0 : a[i][c]);    // explicit reflector: zeros above, unit diagonal
-      }
-      if (nb == W8 && (ld & 1) == 0) {
-#pragma unroll
-        for (int c = 0; c < W8; c += 2) {
-          *reinterpret_cast<double2*>(w + c) = double2{wv[c], wv[c + 1]};
-          *reinterpret_cast<double2*>(v + c) = double2{vv[c], vv[c + 1]};
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < W8; c++) if (c < nb) { w[c] = wv[c]; v[c] = vv[c]; }
-      }
-    }
-  }
-  if (t < 16 * 16) {                                     // the 16 x 16 slot of the enclosing panel
-    const int slot0 = (c0 / 16) * 16, part = (c0 - slot0) / W8;
-    const int i = t / 16, j = t % 16;
-    const long so = blockIdx.x * strideT + (long)(slot0 / 16) * 256;
-    const bool mine = (i / W8 == part) && (j / W8 == part);
-    const double val = (mine && (i % W8) <= (j % W8) && (j % W8) < nb) ? s_T[i % W8][j % W8] : 0.0;
-    Tall[so + t] = val;                                  // live slot: ONLY this part's block (the partial block reflector)
-    if (mine) Tside[so + t] = val;                       // side slot: collects the diagonal blocks of all parts
-  }
-}
-
-// four 4-column quarters: R = 8 rows x 4 columns per lane, 4096 < m <= 8192 rows
-template <int R>
-__global__ __launch_bounds__(1024) void qr_panel_row4(double* __restrict__ Wm, int M, long ld, long strideW,
-                                                     double* __restrict__ Vall, long ldv, long strideV,
-                                                     double* __restrict__ Tall, double* __restrict__ Tside, long strideT,
-                                                     double* __restrict__ taus, long strideTau, int c0, int nb) {
-  constexpr int W8 = 4, NW = 16;                       // columns of this kernel, waves per workgroup
-  __shared__ double s_red[NW];
-  __shared__ double s_w[NW][W8];
-  __shared__ double s_T[W8][W8 + 1];
-  __shared__ double s_Z[W8][W8];
-  __shared__ double s_tau[W8];
-  const int j0 = c0;                                   // rows and columns of this half start at its own diagonal
-  __shared__ double s_alpha;
-  double* A = Wm + blockIdx.x * strideW;
-  double* V = Vall + blockIdx.x * strideV;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool b0 = lane & 1, b1 = lane & 2;
-  const int mycol = (b0 ? 2 : 0) + (b1 ? 1 : 0);                                  // column this lane ends up with
-
-  double a[R][W8];
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + t + 1024 * i;
-#pragma unroll
-    for (int c = 0; c < W8; c++) a[i][c] = 0.0;
-    if (r < M) {
-      const double* src = A + (long)r * ld + j0;
-      if (nb == W8 && (ld & 1) == 0) {                   // 16-byte loads of the lane's own 128-B row segment
-#pragma unroll
-        for (int c = 0; c < W8; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
-      } else {
-#pragma unroll
-        for (int c = 0; c < W8; c++) if (c < nb) a[i][c] = src[c];
-      }
-    }
-  }
-  if (t < W8 * (W8 + 1)) (&s_T[0][0])[t] = 0.0;
-
-  // one column step per compile-time k (generic lambda, see lu.hip: convergent DPP ops block `#pragma unroll`)
-  auto column_step = [&](auto kc) __attribute__((always_inline)) {
-    constexpr int k = decltype(kc)::value;
-    if (k < nb) {
-      const int jc = j0 + k;
-      double part = 0.0;
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 1024 * i;
-        if (r > jc) part += a[i][k] * a[i][k];
-      }
-      if (t == k) s_alpha = a[0][k];
-      part = nd4dpp::wave_sum(part);
-      if (lane == 0) s_red[wave] = part;
-      __syncthreads();
-      double sigma = 0.0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) sigma += s_red[w];
-      const double alpha = s_alpha;
-      double beta = alpha, tau = 0.0, scale = 0.0;
-      if (sigma != 0.0) {
-        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
-        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
-        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
-        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
-        beta = -copysign(nn * ri, alpha);
-        tau = (beta - alpha) * -copysign(ri, alpha);
-        scale = nd4dpp::fast_rcp(alpha - beta);
-      }
-      double vr[R], d[W8];
-#pragma unroll
-      for (int c = 0; c < W8; c++) d[c] = 0.0;
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 1024 * i;
-        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = 0; c < W8; c++) d[c] += vr[i] * a[i][c];
-      }
-      // halving butterfly over the 4 lanes of a group (2 + 1 exchanges), then across the 16 groups of the wave
-      double e2[2], e1;
-#pragma unroll
-      for (int j = 0; j < 2; j++) { const double snd = b0 ? d[j] : d[j + 2], kp = b0 ? d[j + 2] : d[j]; e2[j] = kp + nd4dpp::xor1(snd); }
-      { const double snd = b1 ? e2[0] : e2[1], kp = b1 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor2(snd); }
-      e1 += nd4dpp::xor4(e1);
-      e1 += nd4dpp::xor8(e1);
-      e1 += __shfl_xor(e1, 16);
-      e1 += __shfl_xor(e1, 32);
-      if (lane < W8) s_w[wave][mycol] = e1;
-      __syncthreads();
-      double tot = 0.0;                                   // lane -> column lane & 3
-#pragma unroll
-      for (int w = 0; w < NW; w++) tot += s_w[w][lane & 3];
+      for (int w = 0; w < NW; w++) tot += s_w[w][lane & (W8 - 1)];
       double wv[W8];                                      // wave-uniform totals
 #define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
       ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3)
+      if constexpr (W8 == 8) { ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7) }
 #undef ND4_RL
 #pragma unroll
       for (int i = 0; i < R; i++) {
@@ -662,6 +510,7 @@ __global__ __launch_bounds__(1024) void qr_panel_row4(double* __restrict__ Wm, i
   };
 #define ND4_STEP(K) column_step(std::integral_constant<int, K>{});
   ND4_STEP(0) ND4_STEP(1) ND4_STEP(2) ND4_STEP(3)
+  if constexpr (W8 == 8) { ND4_STEP(4) ND4_STEP(5) ND4_STEP(6) ND4_STEP(7) }
 #undef ND4_STEP
   __syncthreads();
   if (t < nb) {                                          // larft: row t of T depends only on row t
@@ -716,6 +565,7 @@ __global__ __launch_bounds__(1024) void qr_panel_row4(double* __restrict__ Wm, i
     if (mine) Tside[so + t] = val;                       // side slot: collects the diagonal blocks of all parts
   }
 }
+
 
 // ------------------------------------------------------------------------------------ V^T C
 // Wp[chunk][i][j] = sum_{r in chunk} V[r][i] * C[r][j]; V: m x 16 (ldv), C: m x n (ldc).
@@ -1048,9 +898,9 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
       const int w = m <= 4096 ? 8 : 4;
       for (int c = 0; c < nb; c += w) {
         const int nbp = nb - c < w ? nb - c : w;
-        if (w == 8) hipLaunchKernelGGL((qr_panel_row8<4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
+        if (w == 8) hipLaunchKernelGGL((qr_panel_part<4, 8>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
                                        ws.taus, ws.sTau, j0 + c, nbp);
-        else        hipLaunchKernelGGL((qr_panel_row4<8>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
+        else        hipLaunchKernelGGL((qr_panel_part<8, 4>), dim3(batch), dim3(1024), 0, h->stream, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.Tside, ws.sT,
                                        ws.taus, ws.sTau, j0 + c, nbp);
         ND4_HIP(hipGetLastError());
         if (c + w < nb)
