@@ -533,6 +533,22 @@ function makeLa(NDA, fallback) {
     if (U.shape[U.ndim - 2] !== V.shape[V.ndim - 1]) throw new Error('rrqr_solve(Q,R,P, y): System not square.');
     return la.svd_lstsq(U, sv, V, y);
   };
+  /* svd.js:31-63: per matrix the first r with |sv_r| <= sqrt(eps) |sv_0| (entries are only examined up to that point, so a
+     NaN behind the cut does not raise, exactly like the reference's loop). Host side: sv is tiny; a device array is read back. */
+  la.svd_rank = function svd_rank(sv) {
+    sv = la.to_host(asarray(sv));
+    const N = sv.shape[sv.ndim - 1], data = sv.data, count = N > 0 ? data.length / N : 0, r = new Int32Array(count);
+    const EPS = Math.sqrt(dtypeOf(sv) === 'float32' ? 2 ** -23 : 2 ** -52);
+    for (let off = 0; off < count; off++) {
+      const T = EPS * Math.abs(data[N * off]);
+      for (; r[off] < N; r[off]++) {
+        const x = Math.abs(data[N * off + r[off]]);
+        if (!isFinite(x)) throw new Error('svd_rank(): NaN or Infinity encountered.');
+        if (x <= T) break;
+      }
+    }
+    return new NDA(Int32Array.from(sv.shape.subarray(0, sv.ndim - 1)), r);
+  };
   return la;
 }
 
@@ -544,7 +560,7 @@ function install(nd) {
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp, qr_decomp_full: nd.la.qr_decomp_full,
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
-                    qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve,
+                    qr_lstsq: nd.la.qr_lstsq, svd_lstsq: nd.la.svd_lstsq, svd_solve: nd.la.svd_solve, svd_rank: nd.la.svd_rank,
                     cholesky_decomp: nd.la.cholesky_decomp, cholesky_solve: nd.la.cholesky_solve,
                     ldl_decomp: nd.la.ldl_decomp, ldl_solve: nd.la.ldl_solve, hessenberg_decomp: nd.la.hessenberg_decomp, bidiag_decomp: nd.la.bidiag_decomp};
   const acc = makeLa(nd.NDArray, original);

@@ -366,11 +366,15 @@ def qr_lstsq(Q, R, y=None, device=None):
 def svd_rank(sv):
     """svd.js:31-63: per matrix, the first r with |sv_r| <= sqrt(eps) |sv_0| (host side: sv is tiny)."""
     sv = np.asarray(sv, dtype=np.float64)
-    if not np.all(np.isfinite(sv)):
-        raise ValueError("svd_rank(): NaN or Infinity encountered.")
     N = sv.shape[-1]
-    small = np.abs(sv) <= np.sqrt(2.0 ** -52) * np.abs(sv[..., :1])
-    return np.where(small.any(axis=-1), small.argmax(axis=-1), N).astype(np.int32)
+    with np.errstate(invalid="ignore"):
+        small = np.abs(sv) <= np.sqrt(2.0 ** -52) * np.abs(sv[..., :1])
+    rank = np.where(small.any(axis=-1), small.argmax(axis=-1), N).astype(np.int32)
+    # the reference's loop only looks at the entries up to the cut (and at the cut itself): a NaN behind it does not raise
+    seen = np.arange(N) <= rank[..., None]
+    if not np.all(np.isfinite(sv[seen])):
+        raise ValueError("svd_rank(): NaN or Infinity encountered.")
+    return rank
 
 
 def svd_lstsq(U, sv, V=None, y=None, device=None):

@@ -60,6 +60,9 @@ if (mode === 'cpu') {
   assert.throws(() => la.matmul(fill(1, [2, 3]), fill(2, [4, 2]), fill(3, [2, 2])), /Shape mismatch\./);
   assert.throws(() => la.matmul(fill(1, [2, 2, 3]), fill(2, [3, 3, 2]), fill(3, [2, 2])), /broadcast-compatible/);
   { const one = fill(1, [3, 4]); assert.strictEqual(la.matmul(one), one); }
+  { const r = la.svd_rank(new la.NDArray(Int32Array.of(3, 4), Float64Array.of(5, 3, 1e-9, 0,  2, 1, 0.5, 0.25,  1, 1e-20, NaN, 7)));      // svd.js:31-63
+    assert.deepStrictEqual(Array.from(r.data), [2, 4, 1]); assert.deepStrictEqual(Array.from(r.shape), [3]);
+    assert.throws(() => la.svd_rank(new la.NDArray(Int32Array.of(3), Float64Array.of(1, NaN, 0))), /NaN or Infinity/); }
   if (process.argv[3]) {            // chain plans for the golden chain shapes, compared by the Python test with la.chain_plan
     const man = JSON.parse(fs.readFileSync(path.join(process.argv[3], 'manifest.json'))).cases, plans = {};
     for (const [name, m] of Object.entries(man)) if (m.op === 'matmul' && m.shapes.length > 2) plans[name] = la._chain_plan(m.shapes);
@@ -87,6 +90,8 @@ if (mode === 'install') {
       for (let i = 0; i < ref.data.length; i++) assert.ok(mine.data[i] === ref.data[i], 'chain order differs from the reference');
     }
   }
+  { const svs = new nd.NDArray(Int32Array.of(2, 3), Float64Array.of(4, 2, 1e-12, 3, 3, 3));       // same ranks as the reference's svd_rank
+    assert.deepStrictEqual(Array.from(nd2.la.svd_rank(svs).data), Array.from(nd.la.svd_rank(svs).data)); }
   console.log('node install checks ok');
 }
 
@@ -105,7 +110,8 @@ if (mode === 'gpu') {
   { const m = man.mid_svd96, [U, sv, V] = la.svd_decomp(fill(m.seed, m.shape)), ref = npy('mid_svd96', 'sv').data;
     let d = 0; for (let i = 0; i < ref.length; i++) d = Math.max(d, Math.abs(sv.data[i] - ref[i]));
     assert.ok(d <= 1e-12 * ref[0]); assert.deepStrictEqual(Array.from(U.shape), [96, 96]); assert.deepStrictEqual(Array.from(V.shape), [96, 96]);
-    assert.ok(la.last_svd_info.sweeps > 0); }
+    assert.ok(la.last_svd_info.sweeps > 0 && la.last_svd_info.rotations > 0 && la.last_svd_info.offnorm <= 96 * 2.3e-16);
+    assert.deepStrictEqual(Array.from(la.svd_rank(sv).data), [96]); assert.deepStrictEqual(la.devices(), [0]); }
   { const m = man.solve_lu_bcast, A = fill(m.seedA, m.shapeA), Y = fill(m.seedY, m.shapeY);
     const X = la.lu_solve(la.lu_decomp(A), Y), ref = npy('solve_lu_bcast', 'X');
     assert.deepStrictEqual(Array.from(X.shape), ref.shape); assert.ok(relerr(X.data, ref.data) <= 1e-11); }
