@@ -143,7 +143,7 @@ __global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + T * i;
         PivCand o{pivot_mag(a[i][k], r, jc), r};
-        if (r < jc || r >= N) o.mag = -2.0;
+        if ((i == 0 && t < k) || r >= N) o.mag = -2.0;   // r < jc is only possible in row slot 0 of the first k threads
         cand = better(cand, o);
       }
       // wave arg-max on DPP (VALU speed; a ds_bpermute butterfly is six dependent LDS-crossbar round trips): the largest
@@ -191,13 +191,18 @@ __global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N
         }
       }
       // ---- eliminate below the pivot ----
-      const double* u = s_u;                             // broadcast LDS reads (keeps 32 VGPRs free)
+      // The pivot row once into registers (wave-uniform LDS broadcast reads): every row slot uses the same values. Only row slot 0
+      // of the first k+1 threads can hold a row that is already finished (r <= jc <=> i == 0 && t <= k): slots 1.. need no test
+      // at all (rows >= N hold zeros: harmless, never stored), so the update is straight-line code for them — with a test per slot
+      // the compiler re-read the pivot row from LDS inside each of the four divergent branches (32 ds_read_b128 per column).
+      double u[W];
+#pragma unroll
+      for (int c = 0; c < W; c++) u[c] = (c >= k) ? s_u[c] : 0.0;
       const double pk = u[k];
       const double rk = (pk == 0.0 || pk != pk || __builtin_isinf(pk)) ? 1.0 / pk : nd4dpp::fast_rcp(pk);   // 0, Inf, NaN pivots: IEEE semantics
 #pragma unroll
       for (int i = 0; i < R; i++) {
-        const int r = j0 + t + T * i;
-        if (r > jc) {                                    // rows >= N hold zeros: harmless, never stored
+        if (i > 0 || t > k) {
           // a / pivot (lu.js:68) as a * (1/pivot) with one residual correction: the quotient of a division that comes out
           // exact (integer-valued and structured inputs, where later pivot TIES depend on it) is reproduced exactly, any other
           // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division

@@ -309,7 +309,8 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
       ND4_HIP(hipStreamSynchronize(h->stream));
       if (debug) {
         double r; unsigned long long bb = *h_off; memcpy(&r, &bb, 8);
-        fprintf(stderr, "[nd4hip svd] sweep %d: active matrices %u, max |cos| rotated %.3e\n", sweeps, h_active[0], sqrt(r));
+        fprintf(stderr, "[nd4hip svd] sweep %d: active matrices %u, max |cos| found %.3e, rotations so far %llu\n", sweeps, h_active[0], sqrt(r),
+                (unsigned long long)h_off[1]);
       }
       if (h_active[0] == 0) { last_off = *h_off; break; }
       last_off = *h_off;
