@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 512 * i;
-        if (r > jc) part += a[i][k] * a[i][k];
+        if (i > 0 || r > jc) part += a[i][k] * a[i][k];              // row slots >= 1 are always below row jc
       }
       if (t == k) s_alpha = a[0][k];
       part = nd4dpp::wave_sum(part);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 512 * i;
-        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+        vr[i] = (i > 0 || r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
 #pragma unroll
         for (int c = 0; c < NB; c++) d[c] += vr[i] * a[i][c];
       }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
         const double tv = tau * vr[i];
 #pragma unroll
         for (int c = k + 1; c < NB; c++) a[i][c] -= tv * wv[c];
-        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
+        a[i][k] = (i > 0 || r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
       }
       if (t == 0) {
 #pragma unroll
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(1024) void qr_panel_part(double* __restrict__ Wm, i
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 1024 * i;
-        if (r > jc) part += a[i][k] * a[i][k];
+        if (i > 0 || r > jc) part += a[i][k] * a[i][k];              // row slots >= 1 are always below row jc
       }
       if (t == k) s_alpha = a[0][k];
       part = nd4dpp::wave_sum(part);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void qr_panel_part(double* __restrict__ Wm, i
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 1024 * i;
-        vr[i] = (r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+        vr[i] = (i > 0 || r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
 #pragma unroll
         for (int c = 0; c < W8; c++) d[c] += vr[i] * a[i][c];
       }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void qr_panel_part(double* __restrict__ Wm, i
         const double tv = tau * vr[i];
 #pragma unroll
         for (int c = k + 1; c < W8; c++) a[i][c] -= tv * wv[c];
-        a[i][k] = (r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
+        a[i][k] = (i > 0 || r > jc) ? vr[i] : ((r == jc) ? beta : a[i][k]);
       }
       if (t == 0) {
 #pragma unroll
