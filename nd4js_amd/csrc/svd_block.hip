@@ -389,21 +389,21 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen(const double* __restrict
 // with, so G stays consistent with the accumulated Q.
 // Angle formulas: c^2 = (1 + |d|/root)/2, s = g/(root*c), t = s/c, tau = s/(1+c) with d = b - a, root = sqrt(d^2 + 4 g^2): two
 // rsqrt chains and one rcp chain, no IEEE division.
-__global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
-                                                     JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
-                                                     double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                     unsigned long long* __restrict__ offmax, int precheck) {
+__device__ __forceinline__ void eigen_p_body(double* __restrict__ stage_raw, const int pairIdx, const int mat,
+                                             const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                             JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                             double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                             unsigned long long* __restrict__ offmax, int precheck) {
   constexpr int T = 576, TB = 512, NB = 2, NQ = 4;
   constexpr int LD = BB + 1;
   __shared__ double sC[2][BB][LD];        // C(x, y) = G[x][32 + y]
   __shared__ double sB[2][BB][LD];        // B(x, y) = G[32 + x][32 + y] (both triangles)
   __shared__ double sA1[2][BB];           // A(i, i+1): the one entry of the A quadrant the pivot wave needs
   __shared__ double sAng[2][2][BB];       // [round parity][s | tau][pair]
-  __shared__ double stage[PB][PB + 1];    // the summed Gram matrix on entry; afterwards its first 32 rows hold QJ (rows of Q of block J)
+  double (*stage)[PB + 1] = reinterpret_cast<double (*)[PB + 1]>(stage_raw);   // the summed Gram matrix on entry; afterwards its first 32 rows hold QJ (rows of Q of block J)
   __shared__ double sRd[PB];              // 1 / diagonal (pre-check)
   __shared__ unsigned sTotal;
   double (*QJ)[PB + 1] = stage;
-  const int pairIdx = blockIdx.x, mat = blockIdx.y;
   if (st[mat].done) return;
   int I, J;
   nd4_rr_pair(nblk2, step, pairIdx, I, J);
@@ -575,12 +575,15 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
   }
 }
 
-__global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
-                                                   const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
-                                                   const int* __restrict__ flags, long sF_mat, int nchunks) {
-  __shared__ double sQ[PB][PB + 4];
-  const int pairIdx = blockIdx.x, mat = blockIdx.z;
-  int chunk = blockIdx.y;
+// chunk in [0, nchunks): columns of W, [nchunks, 2 nchunks): columns of Ut. T threads load Qt, the first 256 do the products.
+constexpr int SQ_LD = PB + 4;
+constexpr int STAGE_DOUBLES = PB * SQ_LD;            // one LDS array serves as Qt here and as the Gram stage of the rotation kernel
+template <int T, int STRIPS = 4>
+__device__ __forceinline__ void apply_body(double* __restrict__ sq_raw, const int pairIdx, int chunk, const int mat,
+                                           double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
+                                           const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
+                                           const int* __restrict__ flags, long sF_mat, int nchunks) {
+  double (*sQ)[SQ_LD] = reinterpret_cast<double (*)[SQ_LD]>(sq_raw);
   if (st[mat].done || !flags[mat * sF_mat + pairIdx]) return;
   int I, J;
   nd4_rr_pair(nblk2, step, pairIdx, I, J);
@@ -590,13 +593,14 @@ __global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, doubl
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fx = lane & 15, fk = lane >> 4;
   const double* Qt = Qt_all + mat * sQ_mat + (long)pairIdx * (PB * PB);
-  for (int e = t; e < PB * PB; e += 256) sQ[e / PB][e % PB] = Qt[e];
+  for (int e = t; e < PB * PB; e += T) sQ[e / PB][e % PB] = Qt[e];
   __syncthreads();
+  if (T > 256 && t >= 256) return;
   long rowoff[16];                                   // source row of k-step ks for this lane
 #pragma unroll
   for (int ks = 0; ks < 16; ks++) rowoff[ks] = pair_row(ks * 4 + fk, I, J) * N;
-  const int colw = chunk * CH + wave * 64;
-  for (int strip = 0; strip < 4; strip++) {
+  const int colw = chunk * (64 * STRIPS) + wave * (16 * STRIPS);     // nchunks counts chunks of 64 * STRIPS columns
+  for (int strip = 0; strip < STRIPS; strip++) {
     const int cbase = colw + strip * 16;
     if (cbase >= N) break;                           // wave-uniform (N % 16 == 0)
     const int c = cbase + fx;
@@ -615,12 +619,61 @@ __global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, doubl
   }
 }
 
+__global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                                     JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                                     double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                                     unsigned long long* __restrict__ offmax, int precheck) {
+  __shared__ double stage_raw[STAGE_DOUBLES];
+  eigen_p_body(stage_raw, blockIdx.x, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+               offmax, precheck);
+}
+
+__global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
+                                                   const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
+                                                   const int* __restrict__ flags, long sF_mat, int nchunks, int chunk0) {
+  __shared__ double sq_raw[STAGE_DOUBLES];
+  apply_body<256>(sq_raw, blockIdx.x, blockIdx.y + chunk0, blockIdx.z, Wm, Utm, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat, nchunks);
+}
+
+// The W half alone (the deferred form below): narrower column chunks, or the launch has one workgroup per CU and is latency-bound
+template <int STRIPS>
+__global__ __launch_bounds__(256) void jacb_apply_w(double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
+                                                     const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
+                                                     const int* __restrict__ flags, long sF_mat) {
+  __shared__ double sq_raw[STAGE_DOUBLES];
+  apply_body<256, STRIPS>(sq_raw, blockIdx.x, blockIdx.y, blockIdx.z, Wm, nullptr, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat,
+                          (int)gridDim.y);
+}
+
+// Rotation kernel of step `step` + the deferred U update of step - 1 in ONE launch. Only W is on the critical path of a step (the next
+// Gram needs it); Ut <- Qt Ut is independent of everything until the sweep ends. With one large matrix the rotation kernel keeps only
+// npairs workgroups (of 256 CUs) busy for its whole latency-bound run, so the Ut half of the previous step's apply (half of its bytes)
+// rides along as npairs * nchunks extra workgroups of this launch. Qt and flags alternate between two sets by step parity: the
+// rotation workgroups write set step & 1 while the U workgroups read set (step - 1) & 1. (The same overlap through a side stream and
+// events was slower than no overlap: 76 against 64 ms at 2048^2 - the cross-stream dependencies cost more than the overlap gains.)
+__global__ __launch_bounds__(576) void jacb_eigen_pu(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
+                                                      JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
+                                                      double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
+                                                      unsigned long long* __restrict__ offmax, int precheck, int npairs,
+                                                      double* __restrict__ Utm, int N, long sM, const double* __restrict__ Qt_prev,
+                                                      const int* __restrict__ flags_prev) {
+  __shared__ double stage_raw[STAGE_DOUBLES];
+  if ((int)blockIdx.x < npairs) {
+    eigen_p_body(stage_raw, blockIdx.x, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+                 offmax, precheck);
+  } else {
+    const int idx = (int)blockIdx.x - npairs;
+    apply_body<576>(stage_raw, idx % npairs, nchunks + idx / npairs, blockIdx.y, nullptr, Utm, N, sM, nblk, nblk2, step - 1, st, Qt_prev, sQ_mat,
+                    flags_prev, sF_mat, nchunks);
+  }
+}
+
 }  // namespace
 
 size_t nd4_jacobi_block_scratch_doubles(int batch, int N) {
   const int nblk = N / BB, nblk2 = (nblk + 1) & ~1, npairs = nblk2 / 2, nchunks = (N + CH - 1) / CH;
-  const size_t per = (size_t)npairs * nchunks * PB * PB + (size_t)npairs * PB * PB + (size_t)((npairs + 1) / 2 + 1);
-  return per * batch;
+  const size_t per = (size_t)npairs * nchunks * PB * PB + 2 * ((size_t)npairs * PB * PB + (size_t)((npairs + 1) / 2 + 1));
+  return per * batch;                                // Gram partials + two sets of (Qt, flags): see jacb_eigen_pu
 }
 
 int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double* Ut, JacState* st,
@@ -629,9 +682,14 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   const long sM = (long)N * N;
   const long sG = (long)npairs * nchunks * PB * PB, sQ = (long)npairs * PB * PB;
   double* Gpart = scratch;
-  double* Qt = Gpart + (size_t)batch * sG;
-  int* flags = reinterpret_cast<int*>(Qt + (size_t)batch * sQ);
   const long sF = ((npairs + 1) / 2 + 1) * 2;          // ints per matrix
+  double* Qt2[2]; int* flags2[2];
+  Qt2[0] = Gpart + (size_t)batch * sG;
+  flags2[0] = reinterpret_cast<int*>(Qt2[0] + (size_t)batch * sQ);
+  Qt2[1] = Qt2[0] + (size_t)batch * sQ + (size_t)batch * (sF / 2);
+  flags2[1] = reinterpret_cast<int*>(Qt2[1] + (size_t)batch * sQ);
+  static const bool no_defer = getenv("ND4HIP_JAC_NO_DEFER") != nullptr;           // A/B switch
+  const bool defer = !no_defer && (long)batch * npairs <= 64 && N >= 512;            // see jacb_eigen_pu
   for (int step = 0; step < nblk2 - 1; step++) {
     // step 0 of a sweep rotates all pairs of the 64 rows (the pairs inside a block are visited there, once per sweep); the later
     // steps only the 32 x 32 pairs across the two blocks
@@ -640,6 +698,9 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
     // more of them the separate, fully parallel Gram launch hides its load latency better (measured at N = 512:
     // batch 64: 83 -> 52 ms fused; batch 128: 94 -> 102; batch 1024: 738 -> 790)
     const bool fused = N <= 1024 && batch * npairs >= 128 && batch * npairs <= 768;
+    double* Qt = Qt2[defer ? (step & 1) : 0];
+    int* flags = flags2[defer ? (step & 1) : 0];
+    const bool last = step == nblk2 - 2;
     if (fused) {
       hipLaunchKernelGGL((jacb_eigen<true, 8>), dim3((unsigned)npairs, (unsigned)batch), dim3(256), 0, h->stream,
                          W, N, sM, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, cross_only ? 1 : 0);
@@ -651,7 +712,11 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
       else
         hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                            W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
-      if (cross_only) {
+      if (cross_only && defer) {
+        hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(npairs + npairs * nchunks), (unsigned)batch), dim3(576), 0, h->stream,
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, npairs,
+                           Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1]);
+      } else if (cross_only) {
         hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)npairs, (unsigned)batch), dim3(576), 0, h->stream,
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1);
       } else if ((long)batch * npairs <= 256) {            // few workgroups: latency matters, 16 waves hide more of it
@@ -662,8 +727,19 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, 0);
       }
     }
-    hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
-                       W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks);
+    // deferred: W now, Ut with the next step's rotation kernel; the last step of a sweep has no successor and does both
+    // 2048^2: 58.8 ms with 256-column chunks, 57.5 with 128, 57.2 with 64; 4096^2: 322 / 318 / 328
+    static const int wstrips_env = getenv("ND4HIP_JAC_WSTRIPS") ? atoi(getenv("ND4HIP_JAC_WSTRIPS")) : 0;
+    const int wstrips = wstrips_env ? wstrips_env : (N <= 2048 ? 1 : 2);
+    if (defer && !last && wstrips == 1)
+      hipLaunchKernelGGL(jacb_apply_w<1>, dim3((unsigned)npairs, (unsigned)(N / 64), (unsigned)batch), dim3(256), 0, h->stream,
+                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF);
+    else if (defer && !last && wstrips == 2)
+      hipLaunchKernelGGL(jacb_apply_w<2>, dim3((unsigned)npairs, (unsigned)((N + 127) / 128), (unsigned)batch), dim3(256), 0, h->stream,
+                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF);
+    else
+      hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)((defer && !last ? 1 : 2) * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
+                         W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks, 0);
   }
   ND4_HIP(hipGetLastError());
   return 0;
