@@ -45,11 +45,6 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
     e = hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
   }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
-  for (int i = 0; i < 2 && e == hipSuccess; i++) {
-    e = hipEventCreateWithFlags(&h->ev_side_go[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_side_done[i], hipEventDisableTiming);
-  }
   if (e != hipSuccess) { nd4hip_destroy(h); return nd4_hip_fail(e, "stream/event create", __FILE__, __LINE__); }
   h->stream = h->own_stream;
   *out = h;
@@ -65,8 +60,6 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   for (int i = 0; i < 2; i++) { if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]); if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]); }
-  if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
-  for (int i = 0; i < 2; i++) { if (h->ev_side_go[i]) (void)hipEventDestroy(h->ev_side_go[i]); if (h->ev_side_done[i]) (void)hipEventDestroy(h->ev_side_done[i]); }
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (auto& b : h->ws) (void)hipFree(b.p);
   for (auto& b : h->stage) (void)hipFree(b.p);

@@ -24,8 +24,6 @@ struct nd4hip_handle {
   hipEvent_t ev_order = nullptr;      // orders the workspace arena across a change of stream (nd4hip_set_stream)
   hipStream_t copy_stream = nullptr;  // H2D / D2H of the host-pointer entry points (overlaps the kernels on `stream`)
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_chunk[2] = {nullptr, nullptr};   // per staging set: inputs landed / kernels done
-  hipStream_t side_stream = nullptr;  // work that is off the critical path of a factorisation (the U update of a Jacobi step)
-  hipEvent_t ev_side_go[2] = {nullptr, nullptr}, ev_side_done[2] = {nullptr, nullptr};
   std::vector<nd4hip_handle*> peers;  // further devices of a multi-device handle (nd4hip_create_multi); owned
   int num_cu = 256;
   unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)

@@ -211,12 +211,11 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
                                                      double* __restrict__ Vall, long ldv, long strideV,
                                                      double* __restrict__ Tall, long strideT,
                                                      double* __restrict__ taus, long strideTau, int j0, int nb) {
-  __shared__ double s_red[8];
-  __shared__ double s_w[8][NB];
+  __shared__ double s_w[2][8][NB];        // per-wave column sums, double-buffered by column parity (one barrier per column)
+  __shared__ double s_top[2][NB];         // row jc of the tile as it stands before column k's reflector
   __shared__ double s_T[NB][NB + 1];
   __shared__ double s_Z[NB][NB];
   __shared__ double s_tau[NB];
-  __shared__ double s_alpha;
   double* A = Wm + blockIdx.x * strideW;
   double* V = Vall + blockIdx.x * strideV;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -247,39 +246,22 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
     constexpr int k = decltype(kc)::value;
     if (k < nb) {
       const int jc = j0 + k;
-      double part = 0.0;
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 512 * i;
-        if (i > 0 || r > jc) part += a[i][k] * a[i][k];              // row slots >= 1 are always below row jc
-      }
-      if (t == k) s_alpha = a[0][k];
-      part = nd4dpp::wave_sum(part);
-      if (lane == 0) s_red[wave] = part;
-      __syncthreads();
-      double sigma = 0.0;
-#pragma unroll
-      for (int w = 0; w < 8; w++) sigma += s_red[w];
-      const double alpha = s_alpha;
-      double beta = alpha, tau = 0.0, scale = 0.0;
-      if (sigma != 0.0) {
-        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
-        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
-        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
-        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
-        beta = -copysign(nn * ri, alpha);
-        tau = (beta - alpha) * -copysign(ri, alpha);
-        scale = nd4dpp::fast_rcp(alpha - beta);
-      }
-      double vr[R], d[NB];
+      // ONE reduction per column: p[c] = sum_{r > jc} a[r][k] a[r][c] for all 16 columns. p[k] is the sigma of the reflector, and
+      // with v = (1, scale * a[r > jc][k]) the products v^T a_c are scale * p[c] + a[jc][c] (columns c < k hold earlier
+      // reflectors: the same expression gives the z_k that T needs). The norm used to be a reduction and a barrier of its own.
+      double d[NB];
 #pragma unroll
       for (int c = 0; c < NB; c++) d[c] = 0.0;
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 512 * i;
-        vr[i] = (i > 0 || r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
+        const double ak = (i > 0 || r > jc) ? a[i][k] : 0.0;           // row slots >= 1 are always below row jc
 #pragma unroll
-        for (int c = 0; c < NB; c++) d[c] += vr[i] * a[i][c];
+        for (int c = 0; c < NB; c++) d[c] += ak * a[i][c];
+      }
+      if (t == k) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) s_top[k & 1][c] = a[0][c];
       }
       // halving butterfly over the 16 lanes of a group, then across the 4 groups of the wave
       double e8[8], e4[4], e2[2], e1;
@@ -292,19 +274,34 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
       { const double snd = b3 ? e2[0] : e2[1], kp = b3 ? e2[1] : e2[0]; e1 = kp + nd4dpp::xor8(snd); }
       e1 += __shfl_xor(e1, 16);
       e1 += __shfl_xor(e1, 32);
-      if (lane < NB) s_w[wave][mycol] = e1;
+      if (lane < NB) s_w[k & 1][wave][mycol] = e1;
       __syncthreads();
       double tot = 0.0;                                   // lane -> column lane & 15
 #pragma unroll
-      for (int w = 0; w < 8; w++) tot += s_w[w][lane & 15];
+      for (int w = 0; w < 8; w++) tot += s_w[k & 1][w][lane & 15];
       double wv[NB];                                      // wave-uniform totals
 #define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
       ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3) ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7)
       ND4_RL(8) ND4_RL(9) ND4_RL(10) ND4_RL(11) ND4_RL(12) ND4_RL(13) ND4_RL(14) ND4_RL(15)
 #undef ND4_RL
+      const double sigma = wv[k], alpha = s_top[k & 1][k];
+      double beta = alpha, tau = 0.0, scale = 0.0;
+      if (sigma != 0.0) {
+        // sqrt and the two divisions sit on the column's critical path (~100 dependent instructions): one rsqrt and one
+        // rcp with two Newton steps each instead. The work copy is normalised to max|a| in [1,2), so nothing over/underflows;
+        // a few ulp in (beta, tau, scale) perturb H by a few ulp, like the rounding of the update itself.
+        const double nn = alpha * alpha + sigma, ri = nd4dpp::fast_rsqrt(nn);
+        beta = -copysign(nn * ri, alpha);
+        tau = (beta - alpha) * -copysign(ri, alpha);
+        scale = nd4dpp::fast_rcp(alpha - beta);
+      }
+#pragma unroll
+      for (int c = 0; c < NB; c++) wv[c] = fma(scale, wv[c], s_top[k & 1][c]);       // v^T a_c
+      double vr[R];
 #pragma unroll
       for (int i = 0; i < R; i++) {
         const int r = j0 + t + 512 * i;
+        vr[i] = (i > 0 || r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
         const double tv = tau * vr[i];
 #pragma unroll
         for (int c = k + 1; c < NB; c++) a[i][c] -= tv * wv[c];
