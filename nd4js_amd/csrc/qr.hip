@@ -207,17 +207,17 @@ __global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M,
 //                                       column, and the 16 totals come back as wave-uniform readlane values
 //   update a[r][c>k] -= tau v_r d[c];  a[r][k] = v_r;  z_k = d[c<k] feeds T.
 template <int R>
-__global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int M, long ld, long strideW,
-                                                     double* __restrict__ Vall, long ldv, long strideV,
-                                                     double* __restrict__ Tall, long strideT,
-                                                     double* __restrict__ taus, long strideTau, int j0, int nb) {
+__device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restrict__ Wm, int M, long ld, long strideW,
+                                                  double* __restrict__ Vall, long ldv, long strideV,
+                                                  double* __restrict__ Tall, long strideT,
+                                                  double* __restrict__ taus, long strideTau, int j0, int nb) {
   __shared__ double s_w[2][8][NB];        // per-wave column sums, double-buffered by column parity (one barrier per column)
   __shared__ double s_top[2][NB];         // row jc of the tile as it stands before column k's reflector
   __shared__ double s_T[NB][NB + 1];
   __shared__ double s_Z[NB][NB];
   __shared__ double s_tau[NB];
-  double* A = Wm + blockIdx.x * strideW;
-  double* V = Vall + blockIdx.x * strideV;
+  double* A = Wm + mat * strideW;
+  double* V = Vall + mat * strideV;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
   const int mycol = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);   // column this lane ends up with
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
 #pragma unroll
         for (int c = 0; c < NB; c++) if (c < k) s_Z[k][c] = wv[c];
         s_tau[k] = tau;
-        taus[blockIdx.x * strideTau + j0 + k] = tau;
+        taus[mat * strideTau + j0 + k] = tau;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -365,8 +365,223 @@ __global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int
   }
   if (t < NB * NB) {
     const int i = t / NB, j = t % NB;
-    Tall[blockIdx.x * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
+    Tall[mat * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
   }
+}
+
+template <int R>
+__global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                     double* __restrict__ Vall, long ldv, long strideV,
+                                                     double* __restrict__ Tall, long strideT,
+                                                     double* __restrict__ taus, long strideTau, int j0, int nb) {
+  qr_panel_row_body<R>(blockIdx.x, Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
+}
+
+// ---- look-ahead: the block reflector applied to ONE block of <= 16 columns by ONE workgroup ----
+// C (m rows x nc columns) <- (I - V op(T) V^T) C is local to a column: X = V^T C (16 x nc; the waves split the rows, fixed-order
+// LDS reduction), W = op(T) X, C -= V W, all on fp64 MFMA 16x16x4 fed straight from global memory. Because no other workgroup is
+// involved, the update of the columns BEHIND the next panel can run in the same launch as the next panel's factorisation
+// (qr_panel_row_la: the panel kernel keeps one workgroup busy for 30-50 us and the rest of the chip used to idle), and only the 16
+// columns of the next panel itself are updated on the critical path (qr_update_narrow, one workgroup of 1024 threads).
+// V: rows relative to the panel's first row, explicit zeros above the unit diagonal. s_X: NW * 256 + 256 doubles, s_Tm: 16 x 17.
+template <int NT>
+__device__ __forceinline__ void qr_colblock_update(double* __restrict__ s_X, double (*s_Tm)[NB + 1], const double* __restrict__ Tg, int trans,
+                                                   const double* __restrict__ V, long ldv, double* __restrict__ C, long ldc, int m, int nc) {
+  constexpr int NW = NT / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  if (t < NB * NB) s_Tm[t / NB][t % NB] = Tg[t];
+  const int rpw = ((m + NW * 16 - 1) / (NW * 16)) * 16;            // rows per wave, a multiple of 16
+  const int r0 = wave * rpw, r1 = (r0 + rpw < m) ? r0 + rpw : m;
+  const bool cok = fx < nc;
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+  for (int rb = r0; rb < r1; rb += 64) {                           // 16 k-steps per batch: 32 loads in flight per lane
+    double a[16], b[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      const int r = rb + kk * 4 + fk;
+      const bool ok = r < r1;
+      a[kk] = ok ? V[(long)r * ldv + fx] : 0.0;
+      b[kk] = (ok && cok) ? C[(long)r * ldc + fx] : 0.0;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk + 1], b[kk + 1], acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_X[wave * 256 + (fk + 4 * r) * 16 + fx] = acc0[r] + acc1[r];     // X[i = fk + 4r][j = fx]
+  __syncthreads();
+  double* s_Xs = s_X + NW * 256;                                  // the summed X, then W in its place
+  if (t < 256) {
+    double x = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) x += s_X[w * 256 + t];           // fixed order
+    s_Xs[t] = x;
+  }
+  __syncthreads();
+  double wv = 0.0;
+  if (t < 256) {
+    const int i = t / 16, j = t % 16;
+    if (trans) {
+#pragma unroll
+      for (int l = 0; l < NB; l++) if (l <= i) wv += s_Tm[l][i] * s_Xs[l * 16 + j];
+    } else {
+#pragma unroll
+      for (int l = 0; l < NB; l++) if (l >= i) wv += s_Tm[i][l] * s_Xs[l * 16 + j];
+    }
+  }
+  __syncthreads();
+  if (t < 256) s_Xs[t] = -wv;                                     // -W[i][j]
+  __syncthreads();
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_Xs[(kk * 4 + fk) * 16 + fx];
+  for (int rt = r0; rt < r1; rt += 64) {                          // four 16-row tiles per batch
+    double av[4][4]; d4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ra = rt + q * 16 + fx;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < r1) ? V[(long)ra * ldv + kk * 4 + fk] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        c[q][r] = (rc < r1 && cok) ? C[(long)rc * ldc + fx] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        if (rc < r1 && cok) C[(long)rc * ldc + fx] = c[q][r];
+      }
+    }
+  }
+}
+
+// The 16 columns of the NEXT panel are on the critical path, and one workgroup is bound there by the MFMA rate of a single CU
+// (2 x 1 MFLOP at 2048 rows = 2 x 3.9 us; the one-workgroup form took 20 us per panel). Two small launches instead, the rows split over
+// workgroups of 256: (x) partial X = V^T C per workgroup, (apply) every workgroup adds the partials in the same fixed order, forms
+// W = op(T) X itself and updates its own rows. No device-scope fence: the launch boundary is the synchronisation.
+__global__ __launch_bounds__(256) void qr_narrow_x(const double* __restrict__ Wm, int M, int N, long ld, long strideW,
+                                                    const double* __restrict__ Vall, long ldv, long strideV, int pj0, int c0,
+                                                    double* __restrict__ Xp, long strideXp) {
+  __shared__ double s_X[4 * 256];
+  const int mat = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int m = M - pj0, nc = N - c0 < NB ? N - c0 : NB;
+  const double* V = Vall + mat * strideV + (long)pj0 * ldv + pj0;
+  const double* C = Wm + mat * strideW + (long)pj0 * ld + c0;
+  const int rb = blockIdx.x * 256 + wave * 64;
+  const bool cok = fx < nc;
+  double a[16], b[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int r = rb + kk * 4 + fk;
+    const bool ok = r < m;
+    a[kk] = ok ? V[(long)r * ldv + fx] : 0.0;
+    b[kk] = (ok && cok) ? C[(long)r * ld + fx] : 0.0;
+  }
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 2) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk + 1], b[kk + 1], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_X[wave * 256 + (fk + 4 * r) * 16 + fx] = acc0[r] + acc1[r];
+  __syncthreads();
+  Xp[mat * strideXp + (long)blockIdx.x * 256 + t] = ((s_X[t] + s_X[256 + t]) + s_X[512 + t]) + s_X[768 + t];
+}
+__global__ __launch_bounds__(256) void qr_narrow_apply(double* __restrict__ Wm, int M, int N, long ld, long strideW,
+                                                        const double* __restrict__ Vall, long ldv, long strideV,
+                                                        const double* __restrict__ Tall, long strideT, int pj0, int c0,
+                                                        const double* __restrict__ Xp, long strideXp) {
+  __shared__ double s_Xs[256];
+  __shared__ double s_Tm[NB][NB + 1];
+  const int mat = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int m = M - pj0, nc = N - c0 < NB ? N - c0 : NB;
+  const double* V = Vall + mat * strideV + (long)pj0 * ldv + pj0;
+  double* C = Wm + mat * strideW + (long)pj0 * ld + c0;
+  const int rt = blockIdx.x * 256 + wave * 64;
+  const bool cok = fx < nc;
+  // this workgroup's rows first: their latency overlaps the small W computation
+  double av[4][4]; d4 c[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = rt + q * 16 + fx;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < m) ? V[(long)ra * ldv + kk * 4 + fk] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      c[q][r] = (rc < m && cok) ? C[(long)rc * ld + fx] : 0.0;
+    }
+  }
+  s_Tm[t / NB][t % NB] = Tall[mat * strideT + (long)(pj0 / NB) * NB * NB + t];
+  double x = 0.0;
+  for (int g = 0; g < (int)gridDim.x; g++) x += Xp[mat * strideXp + (long)g * 256 + t];     // fixed order, the same in every workgroup
+  s_Xs[t] = x;
+  __syncthreads();
+  double wv = 0.0;
+  {
+    const int i = t / 16, j = t % 16;
+#pragma unroll
+    for (int l = 0; l < NB; l++) if (l <= i) wv += s_Tm[l][i] * s_Xs[l * 16 + j];            // T^T X
+  }
+  __syncthreads();
+  s_Xs[t] = -wv;
+  __syncthreads();
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_Xs[(kk * 4 + fk) * 16 + fx];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      if (rc < m && cok) C[(long)rc * ld + fx] = c[q][r];
+    }
+  }
+}
+
+// panel `pnl` (first row/column j0, workgroup 0 of a matrix) together with the previous panel's block reflector applied to the columns
+// from `wc0` on, one workgroup per block of 16 columns (workgroups 1..). trans = 1 throughout (H^T C during the factorisation).
+template <int R>
+__global__ __launch_bounds__(512) void qr_panel_row_la(double* __restrict__ Wm, int M, int N, long ld, long strideW,
+                                                        double* __restrict__ Vall, long ldv, long strideV,
+                                                        double* __restrict__ Tall, long strideT,
+                                                        double* __restrict__ taus, long strideTau, int j0, int nb, int pj0, int wc0) {
+  const int mat = blockIdx.y;
+  if (blockIdx.x == 0) {
+    qr_panel_row_body<R>(mat, Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
+    return;
+  }
+  __shared__ double s_X[8 * 256 + 256];
+  __shared__ double s_Tm[NB][NB + 1];
+  const int c0 = wc0 + ((int)blockIdx.x - 1) * NB;
+  const int nc = N - c0 < NB ? N - c0 : NB;
+  qr_colblock_update<512>(s_X, s_Tm, Tall + mat * strideT + (long)(pj0 / NB) * NB * NB, 1,
+                          Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Wm + mat * strideW + (long)pj0 * ld + c0, ld, M - pj0, nc);
+}
+// the block reflector of the panel at pj0 applied to the column blocks from wc0 on (grid.x blocks): wide form (512 threads per block
+// of 16 columns) and narrow form (ONE block on 1024 threads: the next panel's columns, on the critical path)
+template <int NT>
+__global__ __launch_bounds__(NT) void qr_update_blocks(double* __restrict__ Wm, int M, int N, long ld, long strideW,
+                                                        const double* __restrict__ Vall, long ldv, long strideV,
+                                                        const double* __restrict__ Tall, long strideT, int pj0, int wc0) {
+  __shared__ double s_X[(NT / 64) * 256 + 256];
+  __shared__ double s_Tm[NB][NB + 1];
+  const int mat = blockIdx.y;
+  const int c0 = wc0 + (int)blockIdx.x * NB;
+  const int nc = N - c0 < NB ? N - c0 : NB;
+  qr_colblock_update<NT>(s_X, s_Tm, Tall + mat * strideT + (long)(pj0 / NB) * NB * NB, 1,
+                         Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Wm + mat * strideW + (long)pj0 * ld + c0, ld, M - pj0, nc);
 }
 
 // ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
@@ -886,6 +1101,36 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   if (M > 2048) ND4_HIP(hipMemsetAsync(ws.Tside, 0, sizeof(double) * (size_t)batch * ws.sT, h->stream));
 
   // ---- factorisation: panels left to right ----
+  // Look-ahead form (every panel fits the thread-per-row kernel): panel p shares its launch with the update of the columns behind
+  // it by reflector p-1; only the 16 columns of panel p+1 are updated between two panels. See qr_colblock_update.
+  static const bool la_off = [] { const char* e = getenv("ND4HIP_QR_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
+  if (!la_off && M <= 2048 && M >= 64) {
+    int pj0 = -1;                                            // first row/column of the previous panel
+    for (int pnl = 0; pnl < npanels; pnl++) {
+      const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
+      // reflector p-1 has reached the 16 columns behind its own panel (the narrow launch: [pj0 + NB, pj0 + 2 NB), which contain this
+      // panel); the columns from there on still lack it
+      const int wide0 = pj0 + 2 * NB, nwide = (pj0 >= 0 && wide0 < N) ? (N - wide0 + NB - 1) / NB : 0;
+      const int wc0 = j0 + nb;
+      const dim3 grid((unsigned)(1 + nwide), (unsigned)batch);
+      if (m <= 512)       hipLaunchKernelGGL(qr_panel_row_la<1>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
+      else if (m <= 1024) hipLaunchKernelGGL(qr_panel_row_la<2>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
+      else                hipLaunchKernelGGL(qr_panel_row_la<4>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
+      if (wc0 < N) {                                           // the next panel's columns (or the first block right of the last panel)
+        const dim3 gn((unsigned)((m + 255) / 256), (unsigned)batch);
+        hipLaunchKernelGGL(qr_narrow_x, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, j0, wc0, ws.Wp, ws.sWb);
+        hipLaunchKernelGGL(qr_narrow_apply, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0, ws.Wp, ws.sWb);
+      }
+      pj0 = j0;
+    }
+    {   // wide input: the last reflector on the columns right of the block the narrow launch has done
+      const int j0 = (npanels - 1) * NB, nb = L - j0 < NB ? L - j0 : NB, wc0 = j0 + nb + NB;
+      if (wc0 < N)
+        hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)((N - wc0 + NB - 1) / NB), (unsigned)batch), dim3(512), 0, h->stream,
+                           W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0);
+    }
+    ND4_HIP(hipGetLastError());
+  } else
   for (int pnl = 0; pnl < npanels; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
     if (m > 2048 && m <= 8192) {
