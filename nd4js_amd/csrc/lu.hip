@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int NB = 16;          // panel width == lanes per row
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct PivCand { double mag; int idx; };
 
@@ -104,14 +105,14 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
 // wave reduction + T/64 LDS partials that every thread finishes itself (no second barrier); the pivot row and the displaced
 // row travel through LDS. The column loop is expanded at compile time, so every register index is static. 2 barriers per column.
 template <int R, int W, int T>
-__global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
+__device__ __forceinline__ void lu_panel_row_body(const int mat, double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                                  int32_t* __restrict__ ipiv, int nopivot) {
   constexpr int NWV = T / 64;
   static_assert(NWV == 8 || NWV == 16, "8 or 16 waves");
   __shared__ PivCand s_red[NWV];
   __shared__ double s_u[W], s_j[W];
-  double* A = LU + blockIdx.x * strideM;
-  int32_t* ip = ipiv + (long)blockIdx.x * N;
+  double* A = LU + mat * strideM;
+  int32_t* ip = ipiv + (long)mat * N;
   const int t = threadIdx.x, wave = t >> 6;
   double a[R][W];
 #pragma unroll
@@ -238,6 +239,192 @@ __global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N
 }
 
 
+template <int R, int W, int T>
+__global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N, long strideM, int j0, int nb,
+                                                       int32_t* __restrict__ P, int32_t* __restrict__ ipiv, int nopivot) {
+  lu_panel_row_body<R, W, T>(blockIdx.x, LU, N, strideM, j0, nb, ipiv, nopivot);
+}
+
+// ---- look-ahead: everything panel pj0 does to ONE block of <= 16 columns outside it, by ONE workgroup ----
+// The 16 row interchanges, U12 = L11^-1 A12 and A22 -= L21 U12 are all local to a column, so one workgroup can take a block of columns
+// through all three without any other workgroup: the update of the columns BEHIND the next panel then runs in the same launch as the
+// next panel's factorisation (lu_panel_row_la: the panel keeps one workgroup busy for 20-37 us while the chip idled), and only the next
+// panel's own 16 columns are updated between two panels (lu_narrow_top + lu_narrow_gemm).
+// The interchanges are not replayed one after the other (a chain of 16 dependent load/store pairs): the rows they touch are the 16 top
+// rows and the <= 16 pivot rows, and what ends up in each of them is found by walking the transpositions backwards (16 compare steps
+// on registers), so it is one gather, a barrier, one scatter. right = false (columns left of the panel): the interchanges only.
+// Pm != nullptr: this workgroup also carries the permutation vector through the same gather (as one more column, lu.js:59-61).
+template <int NT, bool GEMM>
+__device__ __forceinline__ void lu_colblock_update(double* __restrict__ A, int N, int pj0, const int32_t* __restrict__ ip, int do_swap,
+                                                   int c0, int nc, bool right, int32_t* __restrict__ Pm) {
+  __shared__ int s_piv[NB], s_src[2 * NB], s_dst[2 * NB];
+  __shared__ double s_top[NB][NB + 1], s_l[NB][NB + 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  if (t < NB) s_piv[t] = do_swap ? ip[pj0 + t] : pj0 + t;
+  if (right && t >= 256 && t < 512) {                             // L11 (strictly lower, unit diagonal implied)
+    const int i = (t - 256) / NB, j = (t - 256) % NB;
+    s_l[i][j] = (j < i) ? A[(long)(pj0 + i) * N + pj0 + j] : 0.0;
+  }
+  __syncthreads();
+  if (t < 2 * NB) {
+    const int k = t & (NB - 1);
+    const int dst = t < NB ? pj0 + k : s_piv[k];
+    int pos = dst;
+#pragma unroll
+    for (int q = NB - 1; q >= 0; q--) {                           // where the content of row dst comes from: the transpositions backwards
+      const int ps = s_piv[q];
+      pos = (pos == pj0 + q) ? ps : ((pos == ps) ? pj0 + q : pos);
+    }
+    s_src[t] = pos;
+    s_dst[t] = (t < NB || dst >= pj0 + NB) ? dst : -1;             // a pivot row inside the top block is already there as a top row
+  }
+  __syncthreads();
+  double v[(2 * NB * NB + NT - 1) / NT];
+  int32_t pval = 0;
+#pragma unroll
+  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
+    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
+    v[e] = 0.0;
+    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) v[e] = A[(long)s_src[k] * N + c0 + c];
+  }
+  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) pval = Pm[s_src[t]];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
+    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
+    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) {
+      if (right && k < NB) s_top[k][c] = v[e];
+      else A[(long)s_dst[k] * N + c0 + c] = v[e];
+    }
+    if (idx < 2 * NB * NB && c >= nc && k < NB) s_top[k][c] = 0.0;
+  }
+  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) Pm[s_dst[t]] = pval;
+  if (!right) return;
+  __syncthreads();
+  if (t < NB) {                                                   // U12 = L11^-1 A12, one thread per column, same order as lu.js:71-72
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) x[i] = s_top[i][t];
+#pragma unroll
+    for (int i = 1; i < NB; i++) {
+      double acc = x[i];
+#pragma unroll
+      for (int j = 0; j < i; j++) acc -= s_l[i][j] * x[j];
+      x[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      s_top[i][t] = x[i];
+      if (t < nc) A[(long)(pj0 + i) * N + c0 + t] = x[i];
+    }
+  }
+  if constexpr (!GEMM) return;
+  __syncthreads();
+  // A22 -= L21 U12 on fp64 MFMA: the waves split the rows below the top block
+  constexpr int NW = NT / 64;
+  const int m2 = N - pj0 - NB;
+  const int rpw = ((m2 + NW * 16 - 1) / (NW * 16)) * 16;
+  const int r0 = wave * rpw, r1 = (r0 + rpw < m2) ? r0 + rpw : m2;
+  const bool cok = fx < nc;
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = -s_top[kk * 4 + fk][fx];
+  const double* Lp = A + (long)(pj0 + NB) * N + pj0;
+  double* Cp = A + (long)(pj0 + NB) * N + c0;
+  for (int rt = r0; rt < r1; rt += 64) {                          // four 16-row tiles per batch
+    double av[4][4]; d4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ra = rt + q * 16 + fx;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < r1) ? Lp[(long)ra * N + kk * 4 + fk] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        c[q][r] = (rc < r1 && cok) ? Cp[(long)rc * N + fx] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        if (rc < r1 && cok) Cp[(long)rc * N + fx] = c[q][r];
+      }
+    }
+  }
+}
+
+// which block of columns an update workgroup owns: block 0 = the permutation vector alone, then the blocks left of the panel at pj0
+// (interchanges only), then the blocks from column wide0 on
+template <int NT, bool GEMM>
+__device__ __forceinline__ void lu_update_block(int b, int mat, double* __restrict__ LU, int N, long strideM, int pj0, int wide0,
+                                                const int32_t* __restrict__ ipiv, int do_swap, int32_t* __restrict__ Pm) {
+  double* A = LU + mat * strideM;
+  const int32_t* ip = ipiv + (long)mat * N;
+  const int nleft = pj0 / NB;
+  if (b == 0) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, 0, 0, false, Pm + (long)mat * N); return; }
+  b -= 1;
+  if (b < nleft) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, b * NB, NB, false, nullptr); return; }
+  const int c0 = wide0 + (b - nleft) * NB;
+  lu_colblock_update<NT, GEMM>(A, N, pj0, ip, do_swap, c0, N - c0 < NB ? N - c0 : NB, true, nullptr);
+}
+
+// panel at j0 (workgroup 0 of a matrix) together with everything the previous panel (at pj0) still owes the other columns
+template <int R>
+__global__ __launch_bounds__(512) void lu_panel_row_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ P,
+                                                        int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0) {
+  if (blockIdx.x == 0) { lu_panel_row_body<R, NB, 512>(blockIdx.y, LU, N, strideM, j0, NB, ipiv, nopivot); return; }
+  lu_update_block<512, true>((int)blockIdx.x - 1, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P);
+}
+// the same update work on its own (the last look-ahead panel's debt)
+__global__ __launch_bounds__(512) void lu_update_blocks(double* __restrict__ LU, int N, long strideM, int32_t* __restrict__ P,
+                                                         const int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0) {
+  lu_update_block<512, true>((int)blockIdx.x, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P);
+}
+// the next panel's own columns [c0, c0 + 16): interchanges + U12 by one workgroup, then the rank-16 update with the rows split over
+// workgroups of 256 (one workgroup is bound by the MFMA rate of its CU)
+__global__ __launch_bounds__(512) void lu_narrow_top(double* __restrict__ LU, int N, long strideM, const int32_t* __restrict__ ipiv,
+                                                      int nopivot, int pj0, int c0) {
+  lu_colblock_update<512, false>(LU + blockIdx.x * strideM, N, pj0, ipiv + (long)blockIdx.x * N, nopivot ? 0 : 1, c0, N - c0 < NB ? N - c0 : NB,
+                                 true, nullptr);
+}
+__global__ __launch_bounds__(256) void lu_narrow_gemm(double* __restrict__ LU, int N, long strideM, int pj0, int c0) {
+  double* A = LU + blockIdx.y * strideM;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int m2 = N - pj0 - NB, nc = N - c0 < NB ? N - c0 : NB;
+  const int rt = blockIdx.x * 256 + wave * 64;
+  const bool cok = fx < nc;
+  const double* Lp = A + (long)(pj0 + NB) * N + pj0;
+  double* Cp = A + (long)(pj0 + NB) * N + c0;
+  double bw[4], av[4][4]; d4 c[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = cok ? -A[(long)(pj0 + kk * 4 + fk) * N + c0 + fx] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = rt + q * 16 + fx;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < m2) ? Lp[(long)ra * N + kk * 4 + fk] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      c[q][r] = (rc < m2 && cok) ? Cp[(long)rc * N + fx] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      if (rc < m2 && cok) Cp[(long)rc * N + fx] = c[q][r];
+    }
+  }
+}
+
 // ---- apply the panel's row swaps to the columns outside the panel, and (fused) U12 = L11^-1 A12 for the columns to
 // its right: both are one-thread-per-column jobs over the same columns, and the 16 swapped-in pivot rows are exactly the
 // rows the triangular solve works on, so they never leave the registers in between. One launch per panel instead of two.
@@ -361,7 +548,36 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   // every panel of a matrix wider than one panel is followed by lu_laswp: P then rides along with it
   const bool p_in_laswp = N > NB;
   if (p_in_laswp) hipLaunchKernelGGL(lu_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, (int)N);
-  for (int j0 = 0, step = NB; j0 < N; j0 += step) {
+  int j_start = 0;
+  // ---- look-ahead form while the panels fit lu_panel_row<R, 16, 512>: see lu_colblock_update ----
+  static const bool la_off = [] { const char* e = getenv("ND4HIP_LU_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
+  if (!la_off && N <= 2048 && N >= 64 + NB && p_in_laswp) {
+    int pj0 = -1;
+    int j0 = 0;
+    for (; N - j0 >= 64; j0 += NB) {
+      const int m = N - j0;
+      // the panel at pj0 has reached its own columns and the 16 behind them (narrow launches: [pj0 + NB, pj0 + 2 NB) = this panel);
+      // it still owes the columns from pj0 + 2 NB on, the columns left of it, and P
+      const int wide0 = pj0 + 2 * NB;
+      const int nupd = pj0 < 0 ? 0 : 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
+      const dim3 grid((unsigned)(1 + nupd), (unsigned)batch);
+      if (m <= 512)       hipLaunchKernelGGL(lu_panel_row_la<1>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
+      else if (m <= 1024) hipLaunchKernelGGL(lu_panel_row_la<2>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
+      else                hipLaunchKernelGGL(lu_panel_row_la<4>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
+      const int c0 = j0 + NB;                                // the next panel's columns
+      hipLaunchKernelGGL(lu_narrow_top, dim3((unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, ipiv, nopivot, j0, c0);
+      hipLaunchKernelGGL(lu_narrow_gemm, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, LU, N, strideM, j0, c0);
+      pj0 = j0;
+    }
+    {   // the last look-ahead panel's debt, then the remaining (short) panels the old way
+      const int wide0 = pj0 + 2 * NB;
+      const int nupd = 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
+      hipLaunchKernelGGL(lu_update_blocks, dim3((unsigned)nupd, (unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, P, ipiv, nopivot, pj0, wide0);
+    }
+    ND4_HIP(hipGetLastError());
+    j_start = j0;
+  }
+  for (int j0 = j_start, step = NB; j0 < N; j0 += step) {
     const int m = N - j0;
     // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
     // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
