@@ -556,7 +556,8 @@ template <int R>
 __global__ __launch_bounds__(512) void qr_panel_row_la(double* __restrict__ Wm, int M, int N, long ld, long strideW,
                                                         double* __restrict__ Vall, long ldv, long strideV,
                                                         double* __restrict__ Tall, long strideT,
-                                                        double* __restrict__ taus, long strideTau, int j0, int nb, int pj0, int wc0) {
+                                                        double* __restrict__ taus, long strideTau, int j0, int nb, int pj0, int wc0, int nwide,
+                                                        double* __restrict__ QT, long strideQT) {
   const int mat = blockIdx.y;
   if (blockIdx.x == 0) {
     qr_panel_row_body<R>(mat, Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
@@ -564,24 +565,32 @@ __global__ __launch_bounds__(512) void qr_panel_row_la(double* __restrict__ Wm, 
   }
   __shared__ double s_X[8 * 256 + 256];
   __shared__ double s_Tm[NB][NB + 1];
-  const int c0 = wc0 + ((int)blockIdx.x - 1) * NB;
-  const int nc = N - c0 < NB ? N - c0 : NB;
-  qr_colblock_update<512>(s_X, s_Tm, Tall + mat * strideT + (long)(pj0 / NB) * NB * NB, 1,
-                          Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Wm + mat * strideW + (long)pj0 * ld + c0, ld, M - pj0, nc);
+  const int bx = (int)blockIdx.x - 1;
+  const double* Tg = Tall + mat * strideT + (long)(pj0 / NB) * NB * NB;
+  const double* Vp = Vall + mat * strideV + (long)pj0 * ldv + pj0;
+  if (bx < nwide) {
+    const int c0 = wc0 + bx * NB;
+    qr_colblock_update<512>(s_X, s_Tm, Tg, 1, Vp, ldv, Wm + mat * strideW + (long)pj0 * ld + c0, ld, M - pj0, N - c0 < NB ? N - c0 : NB);
+  } else {
+    // Q^T = H_p^T ... H_0^T I is the same column-local update as the trailing columns ([A | I] -> [R | Q^T]): the reflectors reach an
+    // M x M accumulator in the shadow of the panels instead of being multiplied together after the factorisation
+    const int c0 = (bx - nwide) * NB;
+    qr_colblock_update<512>(s_X, s_Tm, Tg, 1, Vp, ldv, QT + mat * strideQT + (long)pj0 * M + c0, M, M - pj0, M - c0 < NB ? M - c0 : NB);
+  }
 }
 // the block reflector of the panel at pj0 applied to the column blocks from wc0 on (grid.x blocks): wide form (512 threads per block
 // of 16 columns) and narrow form (ONE block on 1024 threads: the next panel's columns, on the critical path)
 template <int NT>
-__global__ __launch_bounds__(NT) void qr_update_blocks(double* __restrict__ Wm, int M, int N, long ld, long strideW,
+__global__ __launch_bounds__(NT) void qr_update_blocks(double* __restrict__ Cm, int M, int ncols, long ld, long strideC,
                                                         const double* __restrict__ Vall, long ldv, long strideV,
                                                         const double* __restrict__ Tall, long strideT, int pj0, int wc0) {
   __shared__ double s_X[(NT / 64) * 256 + 256];
   __shared__ double s_Tm[NB][NB + 1];
   const int mat = blockIdx.y;
   const int c0 = wc0 + (int)blockIdx.x * NB;
-  const int nc = N - c0 < NB ? N - c0 : NB;
+  const int nc = ncols - c0 < NB ? ncols - c0 : NB;
   qr_colblock_update<NT>(s_X, s_Tm, Tall + mat * strideT + (long)(pj0 / NB) * NB * NB, 1,
-                         Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Wm + mat * strideW + (long)pj0 * ld + c0, ld, M - pj0, nc);
+                         Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Cm + mat * strideC + (long)pj0 * ld + c0, ld, M - pj0, nc);
 }
 
 // ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
@@ -1072,7 +1081,13 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   ws.sWb = ws.sChunk * ws.nchunks_max;
   ws.sW2 = ws.sChunk;
   const long sWork = tall ? (long)M * N : 0;
-  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork);
+  static const bool la_off = [] { const char* e = getenv("ND4HIP_QR_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
+  static const bool wy_off = [] { const char* e = getenv("ND4HIP_QR_NO_WY"); return e && *e && *e != '0'; }();
+  static const bool qt_off = [] { const char* e = getenv("ND4HIP_QR_NO_QT"); return e && *e && *e != '0'; }();
+  const bool lookahead = !la_off && M <= 2048 && M >= 64;
+  const bool use_qt = lookahead && !wy_off && !qt_off && batch <= 4 && L >= 256;   // Q^T accumulated in the shadow of the panels
+  const long sQT = use_qt ? (long)M * M : 0;
+  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT);
   size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + 64;
   void* p = nullptr;
   Nd4WsScope scope(h);
@@ -1085,6 +1100,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   ws.Wp = d; d += (size_t)batch * ws.sWb;
   ws.W2 = d; d += (size_t)batch * ws.sW2;
   ws.work = tall ? d : nullptr; d += (size_t)batch * sWork;
+  double* QT = use_qt ? d : nullptr; d += (size_t)batch * sQT;
   ws.flips = reinterpret_cast<int*>(d);
 
   // working matrix: R's buffer when it has A's shape (M <= N), a workspace copy when tall
@@ -1103,19 +1119,20 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   // ---- factorisation: panels left to right ----
   // Look-ahead form (every panel fits the thread-per-row kernel): panel p shares its launch with the update of the columns behind
   // it by reflector p-1; only the 16 columns of panel p+1 are updated between two panels. See qr_colblock_update.
-  static const bool la_off = [] { const char* e = getenv("ND4HIP_QR_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
-  if (!la_off && M <= 2048 && M >= 64) {
+  if (lookahead) {
     int pj0 = -1;                                            // first row/column of the previous panel
+    const int nq = QT ? (M + NB - 1) / NB : 0;
+    if (QT) ND4_TRY(nd4_set_identity(h, M, M, QT, M, batch, sQT));
     for (int pnl = 0; pnl < npanels; pnl++) {
       const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
       // reflector p-1 has reached the 16 columns behind its own panel (the narrow launch: [pj0 + NB, pj0 + 2 NB), which contain this
       // panel); the columns from there on still lack it
       const int wide0 = pj0 + 2 * NB, nwide = (pj0 >= 0 && wide0 < N) ? (N - wide0 + NB - 1) / NB : 0;
       const int wc0 = j0 + nb;
-      const dim3 grid((unsigned)(1 + nwide), (unsigned)batch);
-      if (m <= 512)       hipLaunchKernelGGL(qr_panel_row_la<1>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
-      else if (m <= 1024) hipLaunchKernelGGL(qr_panel_row_la<2>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
-      else                hipLaunchKernelGGL(qr_panel_row_la<4>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0);
+      const dim3 grid((unsigned)(1 + nwide + (pj0 >= 0 ? nq : 0)), (unsigned)batch);
+      if (m <= 512)       hipLaunchKernelGGL(qr_panel_row_la<1>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, QT, sQT);
+      else if (m <= 1024) hipLaunchKernelGGL(qr_panel_row_la<2>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, QT, sQT);
+      else                hipLaunchKernelGGL(qr_panel_row_la<4>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, QT, sQT);
       if (wc0 < N) {                                           // the next panel's columns (or the first block right of the last panel)
         const dim3 gn((unsigned)((m + 255) / 256), (unsigned)batch);
         hipLaunchKernelGGL(qr_narrow_x, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, j0, wc0, ws.Wp, ws.sWb);
@@ -1129,6 +1146,8 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
         hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)((N - wc0 + NB - 1) / NB), (unsigned)batch), dim3(512), 0, h->stream,
                            W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0);
     }
+    if (QT) hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)nq, (unsigned)batch), dim3(512), 0, h->stream,
+                               QT, M, M, (long)M, sQT, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, (npanels - 1) * NB, 0);
     ND4_HIP(hipGetLastError());
   } else
   for (int pnl = 0; pnl < npanels; pnl++) {
@@ -1176,8 +1195,9 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   }
   // ---- Q = H_0 H_1 ... H_{p-1} [I; 0]: block reflectors applied backwards ----
   const long sQ = (long)M * Lq;
-  static const bool wy_off = [] { const char* e = getenv("ND4HIP_QR_NO_WY"); return e && *e && *e != '0'; }();
-  if (!wy_off && batch <= 4 && L >= 256) {
+  if (use_qt) {
+    ND4_TRY(nd4_transpose(h, Lq, M, QT, M, Q, Lq, batch, sQT, sQ));        // Q = (first Lq rows of Q^T)^T
+  } else if (!wy_off && batch <= 4 && L >= 256) {
     ND4_TRY(form_q_compact_wy(h, ws, batch, M, Lq, npanels, Q, sQ));
   } else {
     ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, batch, sQ));
