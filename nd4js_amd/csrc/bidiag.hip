@@ -208,6 +208,170 @@ __global__ void bd_extract(const double* __restrict__ Wm, int M, int N, double* 
   for (int i = blockIdx.y; i < K; i += gridDim.y) B[(long)i * J + j] = (j == i || j == i + 1) ? W[(long)i * N + j] : 0.0;
 }
 
+// ================================================================ fused form (one large matrix): 3 launches per step ==========
+// With u, tau the left reflector of step i and v the right one, the step is
+//     z = tau A^T u          (A = rows i.., columns i+1..)        column-local: bd2_colpass, one workgroup per 16 columns, z COMPLETE
+//     row i:  r = A[i,:] - z  -> v (reference convention), B[i,i+1]                     every workgroup of bd2_rowpass, redundantly
+//     y = 2 (A - u z^T) v = 2 (A v - u (z.v))                      row-local: bd2_rowpass, one wave per row
+//     A -= u z^T + y v^T                                           bd2_update, one read-modify-write pass (two before)
+// and the left reflector of step i+1 is built in the prologue of the NEXT bd2_colpass by every workgroup from a contiguous copy of
+// column i+1 that bd2_update leaves behind (ucol). Neither z nor y needs a partial-sum launch, the two reflector kernels are gone:
+// 3 dependent launches per step instead of 7, 2 reads + 1 read-modify-write of the trailing block instead of 2 + 2.
+constexpr int BD2_MAX = 4096;      // rows / columns the LDS copies of u and of row i are sized for
+
+__global__ void bd2_init_ucol(const double* __restrict__ W, int M, int N, double* __restrict__ ucol) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < M) ucol[r] = W[(long)r * N];
+}
+
+// left reflector of step i (bd_vec_col's formulas) by every workgroup; workgroup 0 stores it. Then z for 16 columns.
+__global__ __launch_bounds__(256) void bd2_colpass(double* __restrict__ W, int M, int N, int i, double* __restrict__ UL, int K,
+                                                    double* __restrict__ tauL, const double* __restrict__ ucol, double* __restrict__ z) {
+  extern __shared__ double s_u[];                        // [M - i]: u (u_0 = 1)
+  __shared__ double s_red[4];
+  __shared__ double s_zc[16][17];
+  const int t = threadIdx.x, m = M - i;
+  double mx = 0.0;
+  for (int r = 1 + t; r < m; r += 256) mx = fmax(mx, fabs(ucol[i + r]));
+  mx = blk_max(mx, s_red);
+  double tau = 0.0;
+  if (mx == 0.0) {                                       // nothing below the diagonal: H = I, z = 0
+    if (blockIdx.x == 0) {
+      for (int r = t; r < M; r += 256) UL[(long)r * K + i] = (r == i) ? 1.0 : 0.0;
+      if (t == 0) tauL[i] = 0.0;
+    }
+    const int c = i + 1 + blockIdx.x * 16 + t;
+    if (t < 16 && c < N) z[c] = 0.0;
+    return;
+  }
+  {
+    const double alpha = ucol[i];
+    const double sc = fmax(mx, fabs(alpha));
+    double ss = 0.0;
+    for (int r = 1 + t; r < m; r += 256) { const double x = ucol[i + r] / sc; ss += x * x; }
+    ss = blk_sum(ss, s_red);
+    const double a1 = alpha / sc;
+    const double nrm = sqrt(ss + a1 * a1) * sc;
+    const double beta = alpha > 0 ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    const double inv = 1.0 / (alpha - beta);
+    for (int r = t; r < m; r += 256) s_u[r] = (r == 0) ? 1.0 : ucol[i + r] * inv;
+    if (blockIdx.x == 0) {
+      for (int r = t; r < i; r += 256) UL[(long)r * K + i] = 0.0;
+      for (int r = 1 + t; r < m; r += 256) { UL[(long)(i + r) * K + i] = ucol[i + r] * inv; W[(long)(i + r) * N + i] = 0.0; }
+      if (t == 0) { UL[(long)i * K + i] = 1.0; W[(long)i * N + i] = beta; tauL[i] = tau; }
+    }
+  }
+  __syncthreads();
+  const int cx = t & 15, ry = t >> 4;                    // 16 columns x 16 row lanes: a wave reads 4 whole 128-byte row segments
+  const int c = i + 1 + blockIdx.x * 16 + cx;
+  double acc = 0.0;
+  if (c < N) {
+    const double* col = W + (long)i * N + c;
+    int r = ry;
+    for (; r + 7 * 16 < m; r += 8 * 16) {                // 8 loads in flight per thread
+      double x[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) x[q] = col[(long)(r + q * 16) * N];
+#pragma unroll
+      for (int q = 0; q < 8; q++) acc += s_u[r + q * 16] * x[q];
+    }
+    for (; r < m; r += 16) acc += s_u[r] * col[(long)r * N];
+  }
+  s_zc[ry][cx] = acc;
+  __syncthreads();
+  if (t < 16) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) sum += s_zc[q][t];      // fixed order
+    const int cc = i + 1 + blockIdx.x * 16 + t;
+    if (cc < N) z[cc] = tau * sum;
+  }
+}
+
+// right reflector of step i (bd_vec_row's formulas) by every workgroup from r = A[i,:] - z; workgroup 0 stores it and finishes
+// row i. Then y for 4 rows (one wave each). has_right = 0: the step has no right reflector (i + 1 >= N - 1): row i only.
+__global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M, int N, int i, const double* __restrict__ UL, int K,
+                                                    const double* __restrict__ z, double* __restrict__ VR, int* __restrict__ flagR,
+                                                    double* __restrict__ y, int has_right, double* __restrict__ rowfin) {
+  extern __shared__ double s_v[];                        // [N - first]: r, then v
+  __shared__ double s_red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, first = i + 1, n = N - first;
+  const double* rowi = W + (long)i * N;                 // read by every workgroup: its final form goes to rowfin, bd2_update stores it
+  const int r = first + blockIdx.x * 4 + wave;           // this wave's row
+  double m1 = 0.0;
+  for (int j = t; j < n; j += 256) {
+    const double x = rowi[first + j] - z[first + j];     // u_i = 1
+    s_v[j] = x;
+    if (j > 0) m1 = fmax(m1, fabs(x));
+  }
+  m1 = blk_max(m1, s_red);                               // (its barriers publish s_v)
+  if (!has_right || m1 == 0.0) {                         // NORM.max === 0 -> continue (bidiag.js:67): no right reflector
+    if (blockIdx.x == 0) {
+      for (int j = t; j < n; j += 256) rowfin[first + j] = s_v[j];
+      if (has_right) { for (int j = t; j < N; j += 256) VR[(long)i * N + j] = 0.0; if (t == 0) flagR[i] = 0; }
+    }
+    if (r < M && lane == 0) y[r] = 0.0;
+    return;
+  }
+  const double x0 = s_v[0];
+  const double mx = fmax(m1, fabs(x0));
+  double ss = 0.0;
+  for (int j = t; j < n; j += 256) { const double x = s_v[j] / mx; ss += x * x; }
+  ss = blk_sum(ss, s_red);
+  const double nrm = (isfinite(mx) ? sqrt(ss) * mx : mx) * (x0 > 0 ? -1.0 : 1.0);
+  const double head = x0 - nrm;
+  const double mx2 = fmax(m1, fabs(head));
+  double s2 = 0.0;
+  for (int j = 1 + t; j < n; j += 256) { const double x = s_v[j] / mx2; s2 += x * x; }
+  s2 = blk_sum(s2, s_red);
+  { const double x = head / mx2; s2 += x * x; }
+  const double div = sqrt(s2);
+  double zv = 0.0;
+  for (int j = t; j < n; j += 256) {
+    const double vj = (j == 0 ? head : s_v[j]) / mx2 / div;
+    s_v[j] = vj;
+    zv += z[first + j] * vj;
+  }
+  zv = blk_sum(zv, s_red);                               // (publishes v)
+  if (blockIdx.x == 0) {
+    for (int j = t; j < N; j += 256) VR[(long)i * N + j] = (j >= first) ? s_v[j - first] : 0.0;
+    for (int j = 1 + t; j < n; j += 256) rowfin[first + j] = 0.0;
+    if (t == 0) { rowfin[first] = nrm; flagR[i] = 1; }
+  }
+  if (r >= M) return;
+  const double* row = W + (long)r * N + first;
+  double acc = 0.0;
+  int j = lane;
+  for (; j + 7 * 64 < n; j += 8 * 64) {
+    double x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = row[j + q * 64];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc += x[q] * s_v[j + q * 64];
+  }
+  for (; j < n; j += 64) acc += row[j] * s_v[j];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) y[r] = 2.0 * (acc - UL[(long)r * K + i] * zv);
+}
+
+// A[r, c] -= u_r z_c + y_r v_c on rows i+1.., columns i+1..; the updated column i+1 also goes to ucol (next step's reflector)
+__global__ __launch_bounds__(256) void bd2_update(double* __restrict__ W, int M, int N, int i, const double* __restrict__ UL, int K,
+                                                   const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ VR,
+                                                   double* __restrict__ ucol, const double* __restrict__ rowfin) {
+  const int c = i + 1 + blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  if (blockIdx.y == gridDim.y - 1) { W[(long)i * N + c] = rowfin[c]; return; }       // row i, finished by bd2_rowpass
+  const double zc = z[c], vc = VR[(long)i * N + c];
+  const int r0 = i + 1 + blockIdx.y * 16;
+#pragma unroll 4
+  for (int r = r0; r < r0 + 16 && r < M; r++) {
+    const double x = W[(long)r * N + c] - (UL[(long)r * K + i] * zc + y[r] * vc);
+    W[(long)r * N + c] = x;
+    if (c == i + 1) ucol[r] = x;
+  }
+}
+
 struct BdWs { double* z; double* y; double* zpart; long sV, sZ; int ncols_total; };
 
 // X[r0:r1, c0:c1] -= a * (scale * a^T X): a = column acol of A2 (ld lda); gate = tau array (scale and on/off switch)
@@ -264,6 +428,24 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
   ND4_HIP(hipMemsetAsync(flagR, 0, sizeof(int) * (size_t)batch * K, h->stream));
 
   // ---- factorisation ----
+  static const bool fused_off = getenv("ND4HIP_BIDIAG_UNFUSED") != nullptr;          // A/B switch
+  if (!fused_off && batch == 1 && M >= 128 && N >= 128 && M <= BD2_MAX && N <= BD2_MAX) {
+    double* ucol = ws.zpart;                                 // M doubles (the partial sums of the unfused form are not needed)
+    double* rowfin = ucol + mx;                              // N doubles
+    hipLaunchKernelGGL(bd2_init_ucol, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, W, M, N, ucol);
+    for (int i = 0; i < K; i++) {
+      const int nc = N - i - 1, nr = M - i - 1;
+      const int has_right = (i + 1 < N - 1) ? 1 : 0;
+      hipLaunchKernelGGL(bd2_colpass, dim3((unsigned)(nc > 0 ? (nc + 15) / 16 : 1)), dim3(256), sizeof(double) * (size_t)(M - i), h->stream,
+                         W, M, N, i, UL, K, tauL, ucol, ws.z);
+      if (nc <= 0) continue;
+      hipLaunchKernelGGL(bd2_rowpass, dim3((unsigned)(nr > 0 ? (nr + 3) / 4 : 1)), dim3(256), sizeof(double) * (size_t)nc, h->stream,
+                         W, M, N, i, UL, K, ws.z, VR, flagR, ws.y, has_right, rowfin);
+      hipLaunchKernelGGL(bd2_update, dim3((unsigned)((nc + 255) / 256), (unsigned)((nr > 0 ? (nr + 15) / 16 : 0) + 1)), dim3(256), 0, h->stream,
+                         W, M, N, i, UL, K, ws.z, ws.y, VR, ucol, rowfin);
+    }
+    ND4_HIP(hipGetLastError());
+  } else
   for (int i = 0; i < K; i++) {
     hipLaunchKernelGGL(bd_vec_col, dim3((unsigned)batch), dim3(256), 0, h->stream, W, M, N, i, UL, K, tauL);
     {

@@ -58,7 +58,8 @@ def test_bidiag_golden(la, golden, name):
 
 
 @pytest.mark.parametrize("M,N", [(1, 1), (2, 2), (3, 3), (33, 33), (64, 64), (200, 200), (512, 512),
-                                 (5, 1), (9, 2), (70, 33), (300, 120), (1, 4), (2, 9), (33, 70), (120, 300), (63, 64), (64, 63)])
+                                 (5, 1), (9, 2), (70, 33), (300, 120), (1, 4), (2, 9), (33, 70), (120, 300), (63, 64), (64, 63),
+                                 (128, 128), (129, 257), (257, 129), (300, 299), (299, 300), (400, 200), (200, 400)])
 def test_bidiag_shapes_vs_oracle(la, M, N):
     a = rng.matrix(6400 + 7 * M + N, M, N)
     u, b, v = la.bidiag_decomp(a)
