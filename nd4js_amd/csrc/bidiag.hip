@@ -213,95 +213,152 @@ __global__ void bd_extract(const double* __restrict__ Wm, int M, int N, double* 
 //     z = tau A^T u          (A = rows i.., columns i+1..)        column-local: bd2_colpass, one workgroup per 16 columns, z COMPLETE
 //     row i:  r = A[i,:] - z  -> v (reference convention), B[i,i+1]                     every workgroup of bd2_rowpass, redundantly
 //     y = 2 (A - u z^T) v = 2 (A v - u (z.v))                      row-local: bd2_rowpass, one wave per row
-//     A -= u z^T + y v^T                                           bd2_update, one read-modify-write pass (two before)
-// and the left reflector of step i+1 is built in the prologue of the NEXT bd2_colpass by every workgroup from a contiguous copy of
-// column i+1 that bd2_update leaves behind (ucol). Neither z nor y needs a partial-sum launch, the two reflector kernels are gone:
-// 3 dependent launches per step instead of 7, 2 reads + 1 read-modify-write of the trailing block instead of 2 + 2.
-constexpr int BD2_MAX = 4096;      // rows / columns the LDS copies of u and of row i are sized for
+//     A -= u z^T + y v^T                                           applied LAZILY by the next step's bd2_colpass, in the same pass
+//                                                                  that forms the next z (column-local: 16 columns x all rows)
+// and the left reflector of step i+1 is built in the prologue of that bd2_colpass by every workgroup from column i+1 as it will be
+// after the update, which the waves of bd2_rowpass leave behind in ucol (each has y_r). Neither z nor y needs a partial-sum launch,
+// the two reflector kernels and the update launch are gone: 2 dependent launches per step instead of 7, and 1 read + 1
+// read-modify-write of the trailing block instead of 2 + 2.
+constexpr int BD2_MAXM = 4096, BD2_MAXN = 3072;      // what the LDS copies of (u, u', y') and of row i are sized for
+
+constexpr int CPT = 1024;          // threads of bd2_colpass: 16 columns x 64 row lanes (with 256 the 128 workgroups were latency-bound: 8 loads per thread in flight)
+template <int NT> __device__ __forceinline__ double blk_max_n(double v, double* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; w++) v = fmax(v, s_red[w]);
+  __syncthreads();
+  return v;
+}
+template <int NT> __device__ __forceinline__ double blk_sum_n(double v, double* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) v += s_red[w];
+  __syncthreads();
+  return v;
+}
 
 __global__ void bd2_init_ucol(const double* __restrict__ W, int M, int N, double* __restrict__ ucol) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < M) ucol[r] = W[(long)r * N];
 }
 
-// left reflector of step i (bd_vec_col's formulas) by every workgroup; workgroup 0 stores it. Then z for 16 columns.
-__global__ __launch_bounds__(256) void bd2_colpass(double* __restrict__ W, int M, int N, int i, double* __restrict__ UL, int K,
-                                                    double* __restrict__ tauL, const double* __restrict__ ucol, double* __restrict__ z) {
-  extern __shared__ double s_u[];                        // [M - i]: u (u_0 = 1)
-  __shared__ double s_red[4];
-  __shared__ double s_zc[16][17];
+// left reflector of step i (bd_vec_col's formulas) by every workgroup; workgroup 0 stores it. Then, for 16 columns and in ONE pass
+// over the rows i..: the pending rank-2 update of step i-1 (A -= u' z'^T + y' v'^T, written back) and z of step i from the updated
+// values. The update of a step thus never has a launch of its own: 2 launches per step.
+__global__ __launch_bounds__(CPT) void bd2_colpass(double* __restrict__ W, int M, int N, int i, double* __restrict__ UL, int K,
+                                                    double* __restrict__ tauL, const double* __restrict__ ucol,
+                                                    const double* __restrict__ zprev, int Pprev, double* __restrict__ znew,
+                                                    int prev, const double* __restrict__ uprev, double* __restrict__ unew, const double* __restrict__ y,
+                                                    const double* __restrict__ VR, const double* __restrict__ rowfin) {
+  // grid (column blocks of 16, row parts): with all rows in one workgroup only N/16 <= 128 workgroups stream the trailing block;
+  // the parts' z go to znew[part][N] and are added (fixed order) by their readers. zprev / znew alternate by step.
+  extern __shared__ double s_u[];                        // [3 rpp]: this part's rows of u (u_0 = 1), then of u' and y' (pending update)
+  __shared__ double s_red[CPT / 64];
+  __shared__ double s_zc[CPT / 16][17];
   const int t = threadIdx.x, m = M - i;
+  const int P = gridDim.y, rpp = (((m + P - 1) / P) + 15) & ~15;
+  const int ra = blockIdx.y * rpp, rb = (ra + rpp < m) ? ra + rpp : m;       // this part's rows [ra, rb) relative to row i
+  double* s_up = s_u + rpp; double* s_yp = s_up + rpp;
+  const bool pend = prev >= 0, lead = blockIdx.x == 0 && blockIdx.y == 0;
+  if (pend) {
+    for (int r = ra + t; r < rb; r += CPT) { s_up[r - ra] = uprev[i + r]; s_yp[r - ra] = y[i + r]; }
+    if (lead)                                             // row i-1, finished by bd2_rowpass (rows >= i are all this launch reads)
+      for (int c = i + t; c < N; c += CPT) W[(long)prev * N + c] = rowfin[c];
+  }
   double mx = 0.0;
-  for (int r = 1 + t; r < m; r += 256) mx = fmax(mx, fabs(ucol[i + r]));
-  mx = blk_max(mx, s_red);
+  for (int r = 1 + t; r < m; r += CPT) mx = fmax(mx, fabs(ucol[i + r]));
+  mx = blk_max_n<CPT>(mx, s_red);
   double tau = 0.0;
   if (mx == 0.0) {                                       // nothing below the diagonal: H = I, z = 0
-    if (blockIdx.x == 0) {
-      for (int r = t; r < M; r += 256) UL[(long)r * K + i] = (r == i) ? 1.0 : 0.0;
-      if (t == 0) tauL[i] = 0.0;
+    for (int r = ra + t; r < rb; r += CPT) s_u[r - ra] = (r == 0) ? 1.0 : 0.0;
+    if (lead) {
+      for (int r = t; r < M; r += CPT) { UL[(long)r * K + i] = (r == i) ? 1.0 : 0.0; unew[r] = (r == i) ? 1.0 : 0.0; }
+      // column i in memory still lacks the pending update: its true values are ucol (zeros below the diagonal here)
+      for (int r = 1 + t; r < m; r += CPT) W[(long)(i + r) * N + i] = 0.0;
+      if (t == 0) { tauL[i] = 0.0; W[(long)i * N + i] = ucol[i]; }
     }
-    const int c = i + 1 + blockIdx.x * 16 + t;
-    if (t < 16 && c < N) z[c] = 0.0;
-    return;
-  }
-  {
+  } else {
     const double alpha = ucol[i];
     const double sc = fmax(mx, fabs(alpha));
     double ss = 0.0;
-    for (int r = 1 + t; r < m; r += 256) { const double x = ucol[i + r] / sc; ss += x * x; }
-    ss = blk_sum(ss, s_red);
+    for (int r = 1 + t; r < m; r += CPT) { const double x = ucol[i + r] / sc; ss += x * x; }
+    ss = blk_sum_n<CPT>(ss, s_red);
     const double a1 = alpha / sc;
     const double nrm = sqrt(ss + a1 * a1) * sc;
     const double beta = alpha > 0 ? -nrm : nrm;
     tau = (beta - alpha) / beta;
     const double inv = 1.0 / (alpha - beta);
-    for (int r = t; r < m; r += 256) s_u[r] = (r == 0) ? 1.0 : ucol[i + r] * inv;
-    if (blockIdx.x == 0) {
-      for (int r = t; r < i; r += 256) UL[(long)r * K + i] = 0.0;
-      for (int r = 1 + t; r < m; r += 256) { UL[(long)(i + r) * K + i] = ucol[i + r] * inv; W[(long)(i + r) * N + i] = 0.0; }
-      if (t == 0) { UL[(long)i * K + i] = 1.0; W[(long)i * N + i] = beta; tauL[i] = tau; }
+    for (int r = ra + t; r < rb; r += CPT) s_u[r - ra] = (r == 0) ? 1.0 : ucol[i + r] * inv;
+    if (lead) {                                           // (unew: contiguous copy of u for bd2_rowpass and the next pending update)
+      for (int r = t; r < i; r += CPT) { UL[(long)r * K + i] = 0.0; unew[r] = 0.0; }
+      for (int r = 1 + t; r < m; r += CPT) { const double ur = ucol[i + r] * inv; UL[(long)(i + r) * K + i] = ur; unew[i + r] = ur; W[(long)(i + r) * N + i] = 0.0; }
+      if (t == 0) { UL[(long)i * K + i] = 1.0; unew[i] = 1.0; W[(long)i * N + i] = beta; tauL[i] = tau; }
     }
   }
   __syncthreads();
-  const int cx = t & 15, ry = t >> 4;                    // 16 columns x 16 row lanes: a wave reads 4 whole 128-byte row segments
+  const int cx = t & 15, ry = t >> 4;                    // 16 columns x CPT/16 row lanes: a wave reads 4 whole 128-byte row segments
   const int c = i + 1 + blockIdx.x * 16 + cx;
   double acc = 0.0;
   if (c < N) {
-    const double* col = W + (long)i * N + c;
+    double* col = W + (long)(i + ra) * N + c;
+    double zc = 0.0;
+    if (pend) for (int q = 0; q < Pprev; q++) zc += zprev[(long)q * N + c];
+    const double vc = pend ? VR[(long)prev * N + c] : 0.0;
+    const int m = rb - ra;                               // (rows of this part from here on)
+    constexpr int RL = CPT / 16, UB = 16;
     int r = ry;
-    for (; r + 7 * 16 < m; r += 8 * 16) {                // 8 loads in flight per thread
-      double x[8];
+    for (; r + (UB - 1) * RL < m; r += UB * RL) {          // UB loads in flight per thread
+      double x[UB];
 #pragma unroll
-      for (int q = 0; q < 8; q++) x[q] = col[(long)(r + q * 16) * N];
+      for (int q = 0; q < UB; q++) x[q] = col[(long)(r + q * RL) * N];
+      if (pend) {
 #pragma unroll
-      for (int q = 0; q < 8; q++) acc += s_u[r + q * 16] * x[q];
+        for (int q = 0; q < UB; q++) { x[q] -= s_up[r + q * RL] * zc + s_yp[r + q * RL] * vc; col[(long)(r + q * RL) * N] = x[q]; }
+      }
+#pragma unroll
+      for (int q = 0; q < UB; q++) acc += s_u[r + q * RL] * x[q];
     }
-    for (; r < m; r += 16) acc += s_u[r] * col[(long)r * N];
+    for (; r < m; r += RL) {
+      double x = col[(long)r * N];
+      if (pend) { x -= s_up[r] * zc + s_yp[r] * vc; col[(long)r * N] = x; }
+      acc += s_u[r] * x;
+    }
   }
   s_zc[ry][cx] = acc;
   __syncthreads();
   if (t < 16) {
     double sum = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) sum += s_zc[q][t];      // fixed order
+    for (int q = 0; q < CPT / 16; q++) sum += s_zc[q][t];      // fixed order
     const int cc = i + 1 + blockIdx.x * 16 + t;
-    if (cc < N) z[cc] = tau * sum;
+    if (cc < N) znew[(long)blockIdx.y * N + cc] = tau * sum;
   }
 }
 
 // right reflector of step i (bd_vec_row's formulas) by every workgroup from r = A[i,:] - z; workgroup 0 stores it and finishes
 // row i. Then y for 4 rows (one wave each). has_right = 0: the step has no right reflector (i + 1 >= N - 1): row i only.
 __global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M, int N, int i, const double* __restrict__ UL, int K,
-                                                    const double* __restrict__ z, double* __restrict__ VR, int* __restrict__ flagR,
-                                                    double* __restrict__ y, int has_right, double* __restrict__ rowfin) {
-  extern __shared__ double s_v[];                        // [N - first]: r, then v
+                                                    const double* __restrict__ zp, int P, double* __restrict__ VR, int* __restrict__ flagR,
+                                                    double* __restrict__ y, int has_right, double* __restrict__ rowfin,
+                                                    const double* __restrict__ ucur, double* __restrict__ ucol) {
+  extern __shared__ double s_v[];                        // [N - first]: r, then v; [N - first]: z
   __shared__ double s_red[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, first = i + 1, n = N - first;
+  double* s_z = s_v + n;
   const double* rowi = W + (long)i * N;                 // read by every workgroup: its final form goes to rowfin, bd2_update stores it
   const int r = first + blockIdx.x * 4 + wave;           // this wave's row
   double m1 = 0.0;
   for (int j = t; j < n; j += 256) {
-    const double x = rowi[first + j] - z[first + j];     // u_i = 1
+    double zj = 0.0;
+    for (int q = 0; q < P; q++) zj += zp[(long)q * N + first + j];             // the row parts of bd2_colpass, fixed order
+    s_z[j] = zj;
+    const double x = rowi[first + j] - zj;               // u_i = 1
     s_v[j] = x;
     if (j > 0) m1 = fmax(m1, fabs(x));
   }
@@ -311,7 +368,7 @@ __global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M
       for (int j = t; j < n; j += 256) rowfin[first + j] = s_v[j];
       if (has_right) { for (int j = t; j < N; j += 256) VR[(long)i * N + j] = 0.0; if (t == 0) flagR[i] = 0; }
     }
-    if (r < M && lane == 0) y[r] = 0.0;
+    if (r < M && lane == 0) { y[r] = 0.0; ucol[r] = W[(long)r * N + first] - ucur[r] * s_z[0]; }   // column i+1 as the next step sees it
     return;
   }
   const double x0 = s_v[0];
@@ -331,7 +388,7 @@ __global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M
   for (int j = t; j < n; j += 256) {
     const double vj = (j == 0 ? head : s_v[j]) / mx2 / div;
     s_v[j] = vj;
-    zv += z[first + j] * vj;
+    zv += s_z[j] * vj;
   }
   zv = blk_sum(zv, s_red);                               // (publishes v)
   if (blockIdx.x == 0) {
@@ -352,24 +409,17 @@ __global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M
   }
   for (; j < n; j += 64) acc += row[j] * s_v[j];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) y[r] = 2.0 * (acc - UL[(long)r * K + i] * zv);
+  if (lane == 0) {
+    const double yr = 2.0 * (acc - ucur[r] * zv);
+    y[r] = yr;
+    ucol[r] = row[0] - ucur[r] * s_z[0] - yr * s_v[0];   // column i+1 with this step's update: the next left reflector is built from it
+  }
 }
 
-// A[r, c] -= u_r z_c + y_r v_c on rows i+1.., columns i+1..; the updated column i+1 also goes to ucol (next step's reflector)
-__global__ __launch_bounds__(256) void bd2_update(double* __restrict__ W, int M, int N, int i, const double* __restrict__ UL, int K,
-                                                   const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ VR,
-                                                   double* __restrict__ ucol, const double* __restrict__ rowfin) {
-  const int c = i + 1 + blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
-  if (blockIdx.y == gridDim.y - 1) { W[(long)i * N + c] = rowfin[c]; return; }       // row i, finished by bd2_rowpass
-  const double zc = z[c], vc = VR[(long)i * N + c];
-  const int r0 = i + 1 + blockIdx.y * 16;
-#pragma unroll 4
-  for (int r = r0; r < r0 + 16 && r < M; r++) {
-    const double x = W[(long)r * N + c] - (UL[(long)r * K + i] * zc + y[r] * vc);
-    W[(long)r * N + c] = x;
-    if (c == i + 1) ucol[r] = x;
-  }
+// the last step's row (no later launch stores it)
+__global__ void bd2_finish_row(double* __restrict__ W, int N, int i, const double* __restrict__ rowfin) {
+  const int c = i + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < N) W[(long)i * N + c] = rowfin[c];
 }
 
 struct BdWs { double* z; double* y; double* zpart; long sV, sZ; int ncols_total; };
@@ -411,7 +461,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
   const int Pmax = (M + GR - 1) / GR;
   Nd4WsScope scope(h);
   void* p = nullptr;
-  const size_t nd = (size_t)batch * ((size_t)M * N + (size_t)M * K + (size_t)K * N + (size_t)K + 2 * (size_t)mx + (size_t)Pmax * mx);
+  const size_t nd = (size_t)batch * ((size_t)M * N + (size_t)M * K + (size_t)K * N + (size_t)K + 2 * (size_t)mx + (size_t)(Pmax + 24) * mx);   // (+24 mx: scratch of the fused form)
   ND4_TRY(nd4_ws_alloc(h, sizeof(double) * nd + sizeof(int) * (size_t)batch * (2 * (size_t)K + 2) + 256, &p));
   double* W = static_cast<double*>(p);
   double* UL = W + (size_t)batch * M * N;
@@ -420,7 +470,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
   BdWs ws;
   ws.z = tauL + (size_t)batch * K; ws.y = ws.z + (size_t)batch * mx; ws.zpart = ws.y + (size_t)batch * mx;
   ws.sV = mx; ws.sZ = (long)Pmax * mx; ws.ncols_total = mx;
-  int* flagR = reinterpret_cast<int*>(ws.zpart + (size_t)batch * Pmax * mx);
+  int* flagR = reinterpret_cast<int*>(ws.zpart + (size_t)batch * (Pmax + 24) * mx);
   int* flips = flagR + (size_t)batch * K + 1;
   const long sW = (long)M * N, sUL = (long)M * K, sVRm = (long)K * N;
   ND4_HIP(hipMemcpyAsync(W, A, sizeof(double) * (size_t)batch * sW, hipMemcpyDeviceToDevice, h->stream));
@@ -429,21 +479,35 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
 
   // ---- factorisation ----
   static const bool fused_off = getenv("ND4HIP_BIDIAG_UNFUSED") != nullptr;          // A/B switch
-  if (!fused_off && batch == 1 && M >= 128 && N >= 128 && M <= BD2_MAX && N <= BD2_MAX) {
+  if (!fused_off && batch == 1 && M >= 128 && N >= 128 && M <= BD2_MAXM && N <= BD2_MAXN) {
     double* ucol = ws.zpart;                                 // M doubles (the partial sums of the unfused form are not needed)
     double* rowfin = ucol + mx;                              // N doubles
+    double* ubuf[2] = {rowfin + mx, rowfin + 2 * mx};        // contiguous u of the previous / the current step
+    constexpr int PMAXZ = 8;
+    double* zbuf[2] = {rowfin + 3 * mx, rowfin + (3 + PMAXZ) * (size_t)mx};     // z in up to PMAXZ row parts, alternating by step
+    int Pprev = 1;
     hipLaunchKernelGGL(bd2_init_ucol, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, W, M, N, ucol);
+    int prev = -1;                                           // step whose rank-2 update and row are still pending
     for (int i = 0; i < K; i++) {
       const int nc = N - i - 1, nr = M - i - 1;
       const int has_right = (i + 1 < N - 1) ? 1 : 0;
-      hipLaunchKernelGGL(bd2_colpass, dim3((unsigned)(nc > 0 ? (nc + 15) / 16 : 1)), dim3(256), sizeof(double) * (size_t)(M - i), h->stream,
-                         W, M, N, i, UL, K, tauL, ucol, ws.z);
+      const int ncb = nc > 0 ? (nc + 15) / 16 : 1;
+      // two row parts (z as two partial sums added by its readers) while one part per column block would leave half of the CUs idle;
+      // more parts cost more than they give (every part repeats the reflector prologue, every reader adds P partials: 4-8 parts
+      // on 256 threads 71 ms against 63 at 2048^2)
+      static const int p_env = getenv("ND4HIP_BD_PARTS") ? atoi(getenv("ND4HIP_BD_PARTS")) : 0;
+      const int P = p_env ? (p_env > PMAXZ ? PMAXZ : p_env) : ((ncb <= 128 && M - i >= 512) ? 2 : 1);
+      const int rpp = ((((M - i) + P - 1) / P) + 15) & ~15;
+      hipLaunchKernelGGL(bd2_colpass, dim3((unsigned)ncb, (unsigned)P), dim3(CPT), sizeof(double) * 3 * (size_t)rpp, h->stream,
+                         W, M, N, i, UL, K, tauL, ucol, zbuf[(i + 1) & 1], Pprev, zbuf[i & 1], prev, ubuf[(i + 1) & 1], ubuf[i & 1], ws.y, VR, rowfin);
+      prev = -1;
       if (nc <= 0) continue;
-      hipLaunchKernelGGL(bd2_rowpass, dim3((unsigned)(nr > 0 ? (nr + 3) / 4 : 1)), dim3(256), sizeof(double) * (size_t)nc, h->stream,
-                         W, M, N, i, UL, K, ws.z, VR, flagR, ws.y, has_right, rowfin);
-      hipLaunchKernelGGL(bd2_update, dim3((unsigned)((nc + 255) / 256), (unsigned)((nr > 0 ? (nr + 15) / 16 : 0) + 1)), dim3(256), 0, h->stream,
-                         W, M, N, i, UL, K, ws.z, ws.y, VR, ucol, rowfin);
+      hipLaunchKernelGGL(bd2_rowpass, dim3((unsigned)(nr > 0 ? (nr + 3) / 4 : 1)), dim3(256), sizeof(double) * 2 * (size_t)nc, h->stream,
+                         W, M, N, i, UL, K, zbuf[i & 1], P, VR, flagR, ws.y, has_right, rowfin, ubuf[i & 1], ucol);
+      prev = i; Pprev = P;
     }
+    if (prev >= 0)                                           // only for M < N: the last step has no rows below, its row is all that is pending
+      hipLaunchKernelGGL(bd2_finish_row, dim3((unsigned)((N - prev - 1 + 255) / 256)), dim3(256), 0, h->stream, W, N, prev, rowfin);
     ND4_HIP(hipGetLastError());
   } else
   for (int i = 0; i < K; i++) {
