@@ -213,56 +213,40 @@ struct HessBlk {
   double *vyp;                   // [row groups x column chunks]: partials of v^T y_raw
   int* skipv;                    // [N]: step i skipped (row already in Hessenberg form)
   double* vrows;                 // [nstore][N]: all reflectors as rows, in processing order (transposed into ws.vstore at the end)
+  double* nextrow;               // [N]: the corrected row of the NEXT step, left behind by hessb_reduce
 };
 
-// step i = k-th of its block: current row i (columns < i), its Householder vector (hessenberg.js:43-56). One workgroup.
-__global__ __launch_bounds__(512) void hessb_vec(const double* __restrict__ H, int N, int i, int k, HessWs ws, HessBlk bk) {
-  constexpr int T = 512;
-  extern __shared__ double s_row[];                   // [N]
-  __shared__ double s_red[2][T / 64];
-  __shared__ double s_vi[NBH], s_yi[NBH];
+// step i = k-th of its block: the Householder vector of row i (hessenberg.js:43-56) from the corrected row x (columns < i), by EVERY
+// workgroup of the read pass, into LDS (s_v[N]); the lead workgroup stores it. x = row i of H (k = 0: the block's updates have been
+// applied by the GEMMs) or what hessb_reduce of the previous step left in bk.nextrow. As a launch of its own (one workgroup) this was
+// 8.9 us of the 27 us per step. Returns false when the step is skipped (row already in Hessenberg form, :46).
+__device__ __forceinline__ bool hessb_reflector(double* __restrict__ s_v, double* s_red, const double* __restrict__ H, int N, int i, int k,
+                                                HessWs ws, HessBlk bk, bool lead) {
+  constexpr int T = 256;
   const int t = threadIdx.x, ii = i - 1;
-  if (t < NBH) { s_vi[t] = (t < k) ? bk.Vt[(long)t * N + i] : 0.0; s_yi[t] = (t < k) ? bk.Yt[(long)t * N + i] : 0.0; }
-  __syncthreads();
+  const double* x = (k == 0) ? H + (long)i * N : bk.nextrow;
   double m1 = 0.0;                                     // max |row[j]|, j < i-1
   for (int c = t; c < i; c += T) {
-    double x = H[(long)i * N + c];
-    // 8 steps at a time, all 16 loads of a group in flight (rows >= k of Wt, Vt are zero: the tail group needs no guard)
-    for (int j0 = 0; j0 < k; j0 += 8) {
-      double wv[8], vv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { wv[u] = bk.Wt[(long)(j0 + u) * N + c]; vv[u] = bk.Vt[(long)(j0 + u) * N + c]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) x -= s_vi[j0 + u] * wv[u] + s_yi[j0 + u] * vv[u];
-    }
-    s_row[c] = x;
-    if (c < ii) m1 = fmax(m1, fabs(x));
+    const double xc = x[c];
+    s_v[c] = xc;
+    if (c < ii) m1 = fmax(m1, fabs(xc));
   }
-  for (int off = 32; off > 0; off >>= 1) m1 = fmax(m1, __shfl_xor(m1, off));
-  if ((t & 63) == 0) s_red[0][t >> 6] = m1;
-  __syncthreads();                                    // also publishes s_row
-  m1 = s_red[0][0];
-#pragma unroll
-  for (int w = 1; w < T / 64; w++) m1 = fmax(m1, s_red[0][w]);
-  double* v = ws.v;
+  m1 = block_max(m1, s_red);                           // (its barriers publish s_v)
   double* vrow = bk.vrows + (long)(N - 1 - i) * N;    // reflector number N-1-i (processing order)
   if (m1 == 0.0) {                                    // NORM.max === 0 -> continue (:46)
-    for (int j = t; j < N; j += T) v[j] = 0.0;
-    if (t == 0) { ws.skip[0] = 1; bk.skipv[i] = 1; }
-    return;
+    if (lead) {
+      for (int j = t; j < N; j += T) ws.v[j] = 0.0;
+      if (t == 0) { ws.skip[0] = 1; bk.skipv[i] = 1; }
+    }
+    return false;
   }
   // ONE scaled sum of squares over the entries left of (i, i-1), S1 = sum (x_j / m1)^2; the two FrobeniusNorm results of
   // hessenberg.js:47-50 follow from it: sum over j <= i-1 of (x_j / mx)^2 = S1 (m1/mx)^2 + (h_ii / mx)^2 (same scaling, so no
   // over/underflow either; rounding-level difference to accumulating them entry by entry)
   double S1 = 0.0;
-  for (int j = t; j < ii; j += T) { const double x = s_row[j] / m1; S1 += x * x; }
-  for (int off = 32; off > 0; off >>= 1) S1 += __shfl_xor(S1, off);
-  if ((t & 63) == 0) s_red[1][t >> 6] = S1;
-  __syncthreads();
-  S1 = 0.0;
-#pragma unroll
-  for (int w = 0; w < T / 64; w++) S1 += s_red[1][w];
-  const double hii0 = s_row[ii];
+  for (int j = t; j < ii; j += T) { const double q = s_v[j] / m1; S1 += q * q; }
+  S1 = block_sum(S1, s_red);
+  const double hii0 = s_v[ii];
   const double mx = fmax(m1, fabs(hii0));
   const double q1 = m1 / mx, q0 = hii0 / mx;
   const double ss = S1 * q1 * q1 + q0 * q0;
@@ -274,21 +258,24 @@ __global__ __launch_bounds__(512) void hessb_vec(const double* __restrict__ H, i
   const double scale = 1.4142135623730951 / div;
   for (int j = t; j < N; j += T) {
     double vj = 0.0;
-    if (j < i) vj = (j == ii ? hii : s_row[j]) / mx2 * scale;                                // :51-52
-    v[j] = vj;
-    vrow[j] = vj;
-    bk.Vt[(long)k * N + j] = vj;
+    if (j < i) vj = (j == ii ? hii : s_v[j]) / mx2 * scale;                                // :51-52
+    s_v[j] = vj;
+    if (lead) { ws.v[j] = vj; vrow[j] = vj; bk.Vt[(long)k * N + j] = vj; }
   }
-  if (t == 0) { ws.skip[0] = 0; bk.skipv[i] = 0; bk.nrm[i] = nrm; }
+  if (lead && t == 0) { ws.skip[0] = 0; bk.skipv[i] = 0; bk.nrm[i] = nrm; }
+  __syncthreads();
+  return true;
 }
 
 // The read pass over H_0[0:i, :]: workgroup (row group g, column chunk c) reads BR rows x BC columns with ONE 16-byte load per
 // thread and row, all in flight at once; x partial [g][columns] (a thread owns its two columns: no reduction), y partial
 // [c][rows] (wave reduction per row). The workgroups past the grid of the pass compute a = W^T v, b = V^T v, c = Y^T v.
 __global__ __launch_bounds__(256) void hessb_pass(const double* __restrict__ H, int N, int i, int k, int ngroups, int nchunks, HessWs ws, HessBlk bk) {
-  if (ws.skip[0]) return;
+  extern __shared__ double s_v[];                                  // [N]: the reflector of this step
+  __shared__ double s_redv[4];
+  if (!hessb_reflector(s_v, s_redv, H, N, i, k, ws, bk, blockIdx.x == 0)) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const double* v = ws.v;
+  const double* v = s_v;
   if ((int)blockIdx.x >= ngroups * nchunks) {                     // ---- the 3 k dot products, one wave each
     const int d = ((int)blockIdx.x - ngroups * nchunks) * 4 + wave;
     if (d >= 3 * k) return;
@@ -339,40 +326,72 @@ __global__ __launch_bounds__(256) void hessb_pass(const double* __restrict__ H, 
 
 // y and w of step (i, k) from the partials of the pass and the corrections; rows k of Yt and Wt. 32 indices per workgroup,
 // 8 thread groups share the partial sums of an index (short chains, fixed order: deterministic).
-__global__ __launch_bounds__(256) void hessb_reduce(int N, int i, int k, int nchunks, HessWs ws, HessBlk bk) {
-  if (ws.skip[0]) return;
+__global__ __launch_bounds__(256) void hessb_reduce(const double* __restrict__ H, int N, int i, int k, int nchunks, int want_next, HessWs ws, HessBlk bk) {
   __shared__ double s_red[4];
   __shared__ double s_a[NBH], s_b[NBH], s_c[NBH];
   __shared__ double s_px[RG][RC], s_py[RG][RC];
+  __shared__ double s_vn[NBH + 1], s_yn[NBH + 1], s_ynp[RG];
   const int t = threadIdx.x;
-  if (t < NBH) { s_a[t] = t < k ? bk.dots[t] : 0.0; s_b[t] = t < k ? bk.dots[NBH + t] : 0.0; s_c[t] = t < k ? bk.dots[2 * NBH + t] : 0.0; }
-  // v^T y_raw from the per-workgroup partials of the pass (fixed order: deterministic)
-  double part = 0.0;
-  for (int j = t; j < ((i + BR - 1) / BR) * nchunks; j += 256) part += bk.vyp[j];
-  double vy = block_sum(part, s_red);                                // (ends with a barrier: s_a, s_b, s_c are visible)
-  for (int j = 0; j < k; j++) vy -= s_a[j] * s_b[j] + s_b[j] * s_c[j];
+  const bool skip = ws.skip[0] != 0;
   const int cidx = t % RC, grp = t / RC;
   const int e = blockIdx.x * RC + cidx;
-  const int P = (i + BR - 1) / BR;
-  double x = 0.0, y = 0.0;
-  if (e < N) {
-    for (int p = grp; p < P; p += RG) x += ws.xpart[(long)p * N + e];
-    // corrections: thread group grp takes the steps j = grp, grp + RG, ...
-    for (int j = grp; j < k; j += RG) {
-      const double wj = bk.Wt[(long)j * N + e], vj = bk.Vt[(long)j * N + e], yj = bk.Yt[(long)j * N + e];
-      x -= wj * s_b[j] + vj * s_c[j];
-      y -= vj * s_a[j] + yj * s_b[j];
+  const int inext = i - 1;                                             // the next step's row
+  double wke = 0.0;                                                    // W_k[e] of this step (0 when skipped)
+  if (t < NBH) { s_a[t] = t < k ? bk.dots[t] : 0.0; s_b[t] = t < k ? bk.dots[NBH + t] : 0.0; s_c[t] = t < k ? bk.dots[2 * NBH + t] : 0.0; }
+  if (!skip) {
+    // v^T y_raw from the per-workgroup partials of the pass (fixed order: deterministic)
+    double part = 0.0;
+    for (int j = t; j < ((i + BR - 1) / BR) * nchunks; j += 256) part += bk.vyp[j];
+    double vy = block_sum(part, s_red);                                // (ends with a barrier: s_a, s_b, s_c are visible)
+    for (int j = 0; j < k; j++) vy -= s_a[j] * s_b[j] + s_b[j] * s_c[j];
+    const int P = (i + BR - 1) / BR;
+    double x = 0.0, y = 0.0;
+    if (e < N) {
+      for (int p = grp; p < P; p += RG) x += ws.xpart[(long)p * N + e];
+      // corrections: thread group grp takes the steps j = grp, grp + RG, ...
+      for (int j = grp; j < k; j += RG) {
+        const double wj = bk.Wt[(long)j * N + e], vj = bk.Vt[(long)j * N + e], yj = bk.Yt[(long)j * N + e];
+        x -= wj * s_b[j] + vj * s_c[j];
+        y -= vj * s_a[j] + yj * s_b[j];
+      }
+      if (e < i) for (int ch = grp; ch < nchunks; ch += RG) y += bk.ypart[(long)ch * N + e];
     }
-    if (e < i) for (int ch = grp; ch < nchunks; ch += RG) y += bk.ypart[(long)ch * N + e];
-  }
-  s_px[grp][cidx] = x; s_py[grp][cidx] = y;
-  __syncthreads();
-  if (grp == 0 && e < N) {
-    double xs = 0.0, ys = 0.0;
+    s_px[grp][cidx] = x; s_py[grp][cidx] = y;
+    // y_k at the next step's row index, by the same thread groups in the same order as its owner computes it (every workgroup needs it)
+    if (want_next && cidx == 0) {
+      double yn = 0.0;
+      for (int j = grp; j < k; j += RG) yn -= bk.Vt[(long)j * N + inext] * s_a[j] + bk.Yt[(long)j * N + inext] * s_b[j];
+      for (int ch = grp; ch < nchunks; ch += RG) yn += bk.ypart[(long)ch * N + inext];
+      s_ynp[grp] = yn;
+    }
+    __syncthreads();
+    if (grp == 0 && e < N) {
+      double xs = 0.0, ys = 0.0;
 #pragma unroll
-    for (int q = 0; q < RG; q++) { xs += s_px[q][cidx]; ys += s_py[q][cidx]; }
-    bk.Wt[(long)k * N + e] = xs - vy * ws.v[e];
-    bk.Yt[(long)k * N + e] = (e < i) ? ys : 0.0;
+      for (int q = 0; q < RG; q++) { xs += s_px[q][cidx]; ys += s_py[q][cidx]; }
+      wke = xs - vy * ws.v[e];
+      bk.Wt[(long)k * N + e] = wke;
+      bk.Yt[(long)k * N + e] = (e < i) ? ys : 0.0;
+    }
+  }
+  if (!want_next) return;
+  // ---- the row the NEXT reflector is built from: H_0[i-1, :] - V[i-1, :] W^T - Y[i-1, :] V^T over the k + 1 steps so far ----
+  if (t <= k && t <= NBH) {
+    if (t < k) { s_vn[t] = bk.Vt[(long)t * N + inext]; s_yn[t] = bk.Yt[(long)t * N + inext]; }
+    else if (skip) { s_vn[t] = 0.0; s_yn[t] = 0.0; }
+    else {
+      double yn = 0.0;
+#pragma unroll
+      for (int q = 0; q < RG; q++) yn += s_ynp[q];
+      s_vn[t] = ws.v[inext]; s_yn[t] = yn;
+    }
+  }
+  __syncthreads();
+  if (grp == 0 && e < inext) {
+    double xr = H[(long)inext * N + e];
+    for (int j = 0; j < k; j++) xr -= s_vn[j] * bk.Wt[(long)j * N + e] + s_yn[j] * bk.Vt[(long)j * N + e];
+    if (!skip) xr -= s_vn[k] * wke + s_yn[k] * ws.v[e];
+    bk.nextrow[e] = xr;
   }
 }
 
@@ -438,13 +457,14 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
     // ---- blocked: NBH steps per block, H untouched inside a block, two GEMMs per block ----
     const int nchunks = (N + BC - 1) / BC;
     void* q = nullptr;
-    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)3 * N * NBH + 3 * NBH + (size_t)N + (size_t)nchunks * N + (size_t)((N + BR - 1) / BR) * nchunks + (size_t)nstore * N) +
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)3 * N * NBH + 3 * NBH + (size_t)N + (size_t)nchunks * N + (size_t)((N + BR - 1) / BR) * nchunks + (size_t)nstore * N + (size_t)N) +
                                 sizeof(int) * (size_t)N + 64, &q));
     HessBlk bk;
     bk.Vt = static_cast<double*>(q); bk.Wt = bk.Vt + (size_t)N * NBH; bk.Yt = bk.Wt + (size_t)N * NBH;
     bk.dots = bk.Yt + (size_t)N * NBH; bk.nrm = bk.dots + 3 * NBH; bk.ypart = bk.nrm + N; bk.vyp = bk.ypart + (size_t)nchunks * N;
     bk.vrows = bk.vyp + (size_t)((N + BR - 1) / BR) * nchunks;
-    bk.skipv = reinterpret_cast<int*>(bk.vrows + (size_t)nstore * N);
+    bk.nextrow = bk.vrows + (size_t)nstore * N;
+    bk.skipv = reinterpret_cast<int*>(bk.nextrow + N);
     ND4_HIP(hipMemsetAsync(bk.skipv, 0, sizeof(int) * (size_t)N, h->stream));
     ND4_HIP(hipMemsetAsync(bk.vrows, 0, sizeof(double) * (size_t)nstore * N, h->stream));
     for (int ihi = N - 1; ihi > 1; ihi -= NBH) {
@@ -452,9 +472,9 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
       ND4_HIP(hipMemsetAsync(bk.Vt, 0, sizeof(double) * (size_t)3 * N * NBH, h->stream));
       for (int i = ihi, k = 0; i >= ilo; i--, k++) {
         const int ngroups = (i + BR - 1) / BR, ndot = (3 * k + 3) / 4;
-        hipLaunchKernelGGL(hessb_vec, dim3(1), dim3(512), (size_t)N * sizeof(double), h->stream, H, N, i, k, ws, bk);
-        hipLaunchKernelGGL(hessb_pass, dim3((unsigned)(ngroups * nchunks + ndot)), dim3(256), 0, h->stream, H, N, i, k, ngroups, nchunks, ws, bk);
-        hipLaunchKernelGGL(hessb_reduce, dim3((unsigned)((N + RC - 1) / RC)), dim3(256), 0, h->stream, N, i, k, nchunks, ws, bk);
+        // two launches per step: the pass builds the reflector itself (every workgroup, from the row hessb_reduce left behind)
+        hipLaunchKernelGGL(hessb_pass, dim3((unsigned)(ngroups * nchunks + ndot)), dim3(256), (size_t)N * sizeof(double), h->stream, H, N, i, k, ngroups, nchunks, ws, bk);
+        hipLaunchKernelGGL(hessb_reduce, dim3((unsigned)((N + RC - 1) / RC)), dim3(256), 0, h->stream, H, N, i, k, nchunks, i > ilo ? 1 : 0, ws, bk);
       }
       ND4_HIP(hipGetLastError());
       const int nk = ihi - ilo + 1;
