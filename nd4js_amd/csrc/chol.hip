@@ -16,6 +16,7 @@
 // UNSCALED panel W = L21 D11 next to L21 so that the trailing update is A22 -= W L21^T on the same tile-skipping GEMM.
 #include "nd4hip_internal.h"
 #include "dpp.h"
+#include <type_traits>
 
 namespace {
 
@@ -30,47 +31,100 @@ __global__ void chol_copy_lower(const double* __restrict__ Sm, double* __restric
   for (int i = blockIdx.y; i < N; i += gridDim.y) Lm[base + (long)i * N + j] = (j <= i) ? Sm[base + (long)i * N + j] : 0.0;
 }
 
-__global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags) {
-  double* A = Lm + (long)blockIdx.x * N * N + (long)j0 * N + j0;
-  __shared__ double s_col[CB];
-  const int i = threadIdx.x;                       // row of the block (lanes >= nb idle but keep the barriers)
+// One wave: lane i keeps row i of the block in registers. Column j: the pivot and then column j of L reach the other lanes as
+// wave-uniform v_readlane values (SGPRs) - no LDS, no barrier (the LDS form with four barriers per column took 15.4 us per block, all of
+// it latency). Entries right of the diagonal are scratch (never stored).
+__device__ __forceinline__ double chol_rl(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void chol_diag_body(const int mat, double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags) {
+  double* A = Lm + (long)mat * N * N + (long)j0 * N + j0;
+  const int i = threadIdx.x;                       // row of the block (lanes >= nb idle)
   double a[CB];
 #pragma unroll
   for (int k = 0; k < CB; k++) a[k] = (i < nb && k <= i && k < nb) ? A[(long)i * N + k] : 0.0;
   bool bad = false;
-#pragma unroll
-  for (int j = 0; j < CB; j++) {
-    if (j < nb) {
-      // pivot: lane j publishes the radicand; every lane forms 1/sqrt itself (rsq + two Newton steps, ~12 dependent
-      // instructions instead of sqrt ~30 + division ~35 on the column's critical path). d = x * rsqrt(x) and
-      // l = a / d = a * rsqrt(x) agree with sqrt / division to a few ulp (parity is to 1e-14 cond, the reference sums with
-      // Kahan anyway); a negative or NaN radicand still gives NaN (the flag). The Newton steps turn rsq(0) = inf and rsq(inf) = 0
-      // into NaN, so those two radicands take the reference's own formulas (cholesky.js:40-41): d = sqrt(x), l = a / d, i.e.
-      // d = +-0 with +-Inf (NaN for 0 / 0) below it, and d = Inf with zeros below it. The branch is wave-uniform.
-      if (i == j) s_col[j] = a[j];
-      __syncthreads();
-      const double x = s_col[j];
+  auto column = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < nb) {                                  // uniform
+      // every lane forms 1/sqrt of the pivot itself (rsq + two Newton steps, ~12 dependent instructions instead of sqrt ~30 +
+      // division ~35 on the column's critical path). d = x * rsqrt(x) and l = a / d = a * rsqrt(x) agree with sqrt / division to a
+      // few ulp (parity is to 1e-14 cond, the reference sums with Kahan anyway); a negative or NaN radicand still gives NaN (the flag).
+      // The Newton steps turn rsq(0) = inf and rsq(inf) = 0 into NaN, so those two radicands take the reference's own formulas
+      // (cholesky.js:40-41): d = sqrt(x), l = a / d, i.e. d = +-0 with +-Inf (NaN for 0 / 0) below it, and d = Inf with zeros below it.
+      const double x = chol_rl(a[j], j);
       double ri = nd4dpp::fast_rsqrt(x), d = x * ri;
       if (__builtin_expect(x == 0.0 || __builtin_isinf(x), 0)) { d = sqrt(x); ri = 1.0 / d; }
-      __syncthreads();
       if (i == j) { bad = bad || (d != d); a[j] = d; }
-      if (i > j && i < nb) a[j] = a[j] * ri;
-      if (i < CB) s_col[i] = a[j];                 // column j of L (rows <= j hold their own earlier values: unused)
-      __syncthreads();
-      if (i > j && i < nb) {
+      if (i > j) a[j] = a[j] * ri;
+      const double aj = (i > j) ? a[j] : 0.0;      // rows <= j are finished
 #pragma unroll
-        for (int k = j + 1; k < CB; k++)
-          if (k <= i) a[k] -= a[j] * s_col[k];
-      }
-      __syncthreads();
+      for (int k = j + 1; k < CB; k++) a[k] -= aj * chol_rl(a[j], k);      // L[k][j] from lane k (lanes >= nb hold zeros)
     }
-  }
+  };
+#define ND4_CC(J) column(std::integral_constant<int, J>{});
+  ND4_CC(0) ND4_CC(1) ND4_CC(2) ND4_CC(3) ND4_CC(4) ND4_CC(5) ND4_CC(6) ND4_CC(7) ND4_CC(8) ND4_CC(9) ND4_CC(10) ND4_CC(11) ND4_CC(12) ND4_CC(13) ND4_CC(14) ND4_CC(15)
+  ND4_CC(16) ND4_CC(17) ND4_CC(18) ND4_CC(19) ND4_CC(20) ND4_CC(21) ND4_CC(22) ND4_CC(23) ND4_CC(24) ND4_CC(25) ND4_CC(26) ND4_CC(27) ND4_CC(28) ND4_CC(29) ND4_CC(30) ND4_CC(31)
+#undef ND4_CC
   if (i < nb) {
 #pragma unroll
     for (int k = 0; k < CB; k++)
       if (k < nb) A[(long)i * N + k] = (k <= i) ? a[k] : 0.0;
   }
-  if (bad) atomicOr(&flags[blockIdx.x], 1);
+  if (bad) atomicOr(&flags[mat], 1);
+}
+__global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags) {
+  chol_diag_body(blockIdx.x, Lm, N, j0, nb, flags);
+}
+
+// ---- look-ahead: the diagonal block of step k (one wave, 15 us of latency) in the same launch as the trailing update of step k-1 ----
+// Workgroup 0 of a matrix factorises A[j0:j0+nb, j0:j0+nb]; the others apply A22 -= L21 L21^T of the PREVIOUS block column (at pj0) to the
+// lower tiles from block column j0 + CB on: 64 x 32 tiles, a wave owns 16 x 32, operands straight from global memory in MFMA layout (NT:
+// both are '4 consecutive doubles of a row'), accumulators start at C. Block column j0 itself got that update between the two launches
+// (the narrow GEMM in nd4_potrf), so the trailing update is off the critical path: per block diag + trsm + narrow instead of diag +
+// trsm + full update.
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags, int pj0, int ntc) {
+  const int mat = blockIdx.y, t = threadIdx.x;
+  if (blockIdx.x == 0) { if (t < 64) chol_diag_body(mat, Lm, N, j0, nb, flags); return; }
+  const int c1 = j0 + CB;                                   // first row / column of the part still lacking update pj0
+  const int tile = (int)blockIdx.x - 1, tr = tile / ntc, tc = tile % ntc;
+  const int row0 = c1 + tr * 64, col0 = c1 + tc * 32;
+  if (col0 > row0 + 63) return;                             // strictly above the diagonal
+  double* Lb = Lm + (long)mat * N * N;
+  const int lane = t & 63, w = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int rb = row0 + 16 * w;
+  if (rb >= N) return;
+  d4 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = rb + fk + 4 * r, col = col0 + 16 * j + fx;
+      acc[j][r] = (row < N && col < N) ? Lb[(long)row * N + col] : 0.0;
+    }
+  double a[8], b[2][8];
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++) {
+    const int ra = rb + fx;
+    a[kk] = (ra < N) ? -Lb[(long)ra * N + pj0 + kk * 4 + fk] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int cr = col0 + 16 * j + fx;                    // row of L that is column cr of L^T
+      b[j][kk] = (cr < N) ? Lb[(long)cr * N + pj0 + kk * 4 + fk] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 8; kk++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[j][kk], acc[j], 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = rb + fk + 4 * r, col = col0 + 16 * j + fx;
+      if (row < N && col < N) Lb[(long)row * N + col] = acc[j][r];
+    }
 }
 
 // rows r in [j0+nb, N): L[r, j0:j0+nb] = A[r, j0:j0+nb] L_kk^-T
@@ -199,16 +253,34 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
   const unsigned gy = (unsigned)(N < 1024 ? N : 1024);
   ND4_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)batch, h->stream));
   hipLaunchKernelGGL(chol_copy_lower, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, S, L, N);
-  for (int j0 = 0; j0 < N; j0 += CB) {
+  static const bool la_off = getenv("ND4HIP_CHOL_NO_LOOKAHEAD") != nullptr;          // A/B switch
+  const bool lookahead = !la_off && N >= 4 * CB && (long)batch * N <= 65536;
+  for (int j0 = 0, pj0 = -1; j0 < N; j0 += CB) {
     const int nb = N - j0 < CB ? N - j0 : CB;
-    hipLaunchKernelGGL(chol_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, L, N, j0, nb, flags);
+    if (lookahead) {
+      // block column j0 is complete (narrow update below); the columns from j0 + CB on still lack the update of block column pj0
+      const int rest = N - (j0 + CB);
+      const int ntr = (pj0 >= 0 && rest > 0) ? (rest + 63) / 64 : 0, ntc = (pj0 >= 0 && rest > 0) ? (rest + 31) / 32 : 1;
+      hipLaunchKernelGGL(chol_diag_la, dim3((unsigned)(1 + ntr * ntc), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb, flags,
+                         pj0 < 0 ? 0 : pj0, ntc);
+    } else {
+      hipLaunchKernelGGL(chol_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, L, N, j0, nb, flags);
+    }
     const int m2 = N - j0 - nb;
     if (m2 <= 0) break;
     hipLaunchKernelGGL(chol_trsm, dim3((unsigned)((m2 + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb);
     ND4_HIP(hipGetLastError());
-    // A22 -= L21 L21^T: one launch, 128x128 tiles strictly above the diagonal are skipped
     const int r0 = j0 + nb;
-    ND4_TRY(nd4_syrk_lower(h, N - r0, nb, -1.0, L + (long)r0 * N + j0, N, sL, 1.0, L + (long)r0 * N + r0, N, sL, batch));
+    if (lookahead) {
+      // only the next block column now: A[r0:, r0:r0+CB] -= L[r0:, j0:j0+CB] L[r0:r0+CB, j0:j0+CB]^T; the rest rides under the next diagonal block
+      const int ncn = N - r0 < CB ? N - r0 : CB;
+      ND4_TRY(nd4_gemm(h, false, true, N - r0, ncn, nb, -1.0, L + (long)r0 * N + j0, N, sL, L + (long)r0 * N + j0, N, sL,
+                       1.0, L + (long)r0 * N + r0, N, sL, batch));
+      pj0 = j0;
+    } else {
+      // A22 -= L21 L21^T: one launch, 128x128 tiles strictly above the diagonal are skipped
+      ND4_TRY(nd4_syrk_lower(h, N - r0, nb, -1.0, L + (long)r0 * N + j0, N, sL, 1.0, L + (long)r0 * N + r0, N, sL, batch));
+    }
   }
   hipLaunchKernelGGL(chol_finish, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, L, N);
   ND4_HIP(hipGetLastError());
