@@ -172,29 +172,26 @@ __global__ __launch_bounds__(256) void chol_trsm(double* __restrict__ Lm, int N,
 // ---- LDL^T ----
 __global__ __launch_bounds__(64) void ldl_diag(double* __restrict__ Lm, int N, int j0, int nb) {
   double* A = Lm + (long)blockIdx.x * N * N + (long)j0 * N + j0;
-  __shared__ double s_col[CB];
-  __shared__ double s_d;
   const int i = threadIdx.x;
   double a[CB];
 #pragma unroll
   for (int k = 0; k < CB; k++) a[k] = (i < nb && k <= i && k < nb) ? A[(long)i * N + k] : 0.0;
-#pragma unroll
-  for (int j = 0; j < CB; j++) {
+  // as chol_diag_body: D_j and the unscaled column V = L[:,j] D_j (ldl.js:52) reach the other lanes as v_readlane values
+  auto column = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
     if (j < nb) {
-      if (i == j) s_d = a[j];                      // D_j (ldl.js:58-59 divides by LD[j,j])
-      if (i < CB) s_col[i] = a[j];                 // V = L[:,j] D_j, the unscaled column (ldl.js:52)
-      __syncthreads();
-      const double d = s_d;
-      if (i > j && i < nb) {
-        const double l = a[j] / d;
+      const double d = chol_rl(a[j], j);            // D_j (ldl.js:58-59 divides by LD[j,j])
+      const bool below = i > j && i < nb;
+      const double l = below ? a[j] / d : 0.0;
 #pragma unroll
-        for (int k = j + 1; k < CB; k++)
-          if (k <= i) a[k] -= l * s_col[k];
-        a[j] = l;
-      }
-      __syncthreads();
+      for (int k = j + 1; k < CB; k++) a[k] -= l * chol_rl(a[j], k);      // V_k from lane k, still unscaled there
+      if (below) a[j] = l;
     }
-  }
+  };
+#define ND4_CC(J) column(std::integral_constant<int, J>{});
+  ND4_CC(0) ND4_CC(1) ND4_CC(2) ND4_CC(3) ND4_CC(4) ND4_CC(5) ND4_CC(6) ND4_CC(7) ND4_CC(8) ND4_CC(9) ND4_CC(10) ND4_CC(11) ND4_CC(12) ND4_CC(13) ND4_CC(14) ND4_CC(15)
+  ND4_CC(16) ND4_CC(17) ND4_CC(18) ND4_CC(19) ND4_CC(20) ND4_CC(21) ND4_CC(22) ND4_CC(23) ND4_CC(24) ND4_CC(25) ND4_CC(26) ND4_CC(27) ND4_CC(28) ND4_CC(29) ND4_CC(30) ND4_CC(31)
+#undef ND4_CC
   if (i < nb) {
 #pragma unroll
     for (int k = 0; k < CB; k++)
