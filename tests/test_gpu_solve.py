@@ -183,3 +183,30 @@ def test_lstsq_errors_match_reference_text(la):
         la.svd_lstsq(np.eye(2), np.array([1.0, np.inf]), np.eye(2), np.ones((2, 1)))
     with pytest.raises(ValueError, match="System not square"):
         la.svd_solve(np.ones((4, 3)), np.ones(3), np.ones((3, 3)), np.ones((4, 1)))
+
+
+@pytest.mark.parametrize("M,J", [(256, 32), (512, 40), (1056, 100), (2080, 33)])
+def test_one_launch_triangular_solve(la, M, J):
+    """M a multiple of 32 with >= 32 right-hand sides takes trsm.hip's column-local kernel (trsm_cols: X in MFMA accumulators, inverted
+    32 x 32 diagonal blocks, panels of 1024 rows with a GEMM in between): both triangles against the oracle's substitution."""
+    y = rng.matrix(3400 + J, M, J)
+    for upper in (False, True):
+        t = triangle(3410 + M, (M, M), upper)
+        x = (la.triu_solve if upper else la.tril_solve)(t, y)
+        ref = (oracle.triu_solve if upper else oracle.tril_solve)(t, y)
+        assert relerr(x, ref) <= 1e-13
+        assert np.abs(t @ x - y).max() <= 1e-12 * M
+
+
+def test_one_launch_triangular_solve_batched_broadcast(la):
+    """leading batch dimensions broadcast (tri.js:155-290): one triangle against a stack of right-hand sides and vice versa"""
+    t = triangle(3420, (512, 512), False)
+    y = rng.matrix(3421, 3, 512, 48)
+    x = la.tril_solve(t, y)
+    for b in range(3):
+        assert relerr(x[b], oracle.tril_solve(t, y[b])) <= 1e-13
+    ts = triangle(3422, (2, 256, 256), True)
+    y1 = rng.matrix(3423, 256, 64)
+    x = la.triu_solve(ts, y1)
+    for b in range(2):
+        assert relerr(x[b], oracle.triu_solve(ts[b], y1)) <= 1e-13
