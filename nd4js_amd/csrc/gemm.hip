@@ -370,7 +370,7 @@ int nd4_gemm(nd4hip_handle* h, bool transA, bool transB, int64_t M, int64_t N, i
   Nd4WsScope scope(h);
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
   int nsplit = 1;
-  if (tiles < 128 && K >= 512) {
+  if (tiles <= 160 && K >= 512) {                       // (<= 160: a launch of 128-160 tiles leaves a third of the 256 CUs idle)
     int64_t want = 384 / tiles;
     if (want > K / 256) want = K / 256;
     if (want > 32) want = 32;

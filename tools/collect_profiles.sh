@@ -14,6 +14,8 @@ ks svd2048 python3 $R/tools/prof_ops.py svd
 ks lu_qr_chol_2048 python3 $R/tools/prof_ops.py lu qr chol
 ks svd_batch256x512 python3 $R/tools/prof_batch.py 256
 ks hess2048 python3 $R/tools/prof_hess.py 2048 hess
+ks bidiag2048 python3 $R/tools/prof_hess.py 2048 bidiag
+ks lu_solve2048 python3 $R/tools/prof_ops.py lusolve
 pmc gemm_fetch FETCH_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_write WRITE_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Profiling driver: runs selected hot-path ops a few times so that
 `rocprofv3 --kernel-trace --stats -- python3 tools/prof_ops.py lu qr` gives per-kernel times.
-usage: prof_ops.py [matmul] [lu] [qr] [chol] [svd] [svdbatch] [--n N] [--reps R]"""
+usage: prof_ops.py [matmul] [lu] [qr] [chol] [svd] [svdbatch] [lusolve] [--n N] [--reps R]"""
 import os
 import sys
 
@@ -30,6 +30,10 @@ def main():
             dev.qr_decomp(A)
         if "svd" in args:
             dev.svd_decomp(A)
+        if "lusolve" in args:
+            if _ == 0:
+                lu_p = dev.lu_decomp(A)
+            dev.lu_solve(lu_p[0], lu_p[1], A)
         if "svdbatch" in args:
             X = dev.fill_uniform(1000, (32, 512, 512))
             dev.svd_decomp(X)
