@@ -22,6 +22,7 @@ namespace {
 
 constexpr int CB = 32;            // block size
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 // L <- tril(S), strict upper <- 0
 __global__ void chol_copy_lower(const double* __restrict__ Sm, double* __restrict__ Lm, int N) {
@@ -37,7 +38,8 @@ __global__ void chol_copy_lower(const double* __restrict__ Sm, double* __restric
 __device__ __forceinline__ double chol_rl(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-__device__ __forceinline__ void chol_diag_body(const int mat, double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags) {
+__device__ __forceinline__ void chol_diag_body(const int mat, double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags,
+                                               double* __restrict__ invout = nullptr) {
   double* A = Lm + (long)mat * N * N + (long)j0 * N + j0;
   const int i = threadIdx.x;                       // row of the block (lanes >= nb idle)
   double a[CB];
@@ -72,6 +74,40 @@ __device__ __forceinline__ void chol_diag_body(const int mat, double* __restrict
       if (k < nb) A[(long)i * N + k] = (k <= i) ? a[k] : 0.0;
   }
   if (bad) atomicOr(&flags[mat], 1);
+  if (invout != nullptr && i < CB) {
+    // L_kk^-1 for chol_trsm_narrow (rows below the block by MFMA): lane j solves L y = e_j, the entries of L arrive as readlane
+    // values. Identity beyond nb.
+    double y[CB];
+#pragma unroll
+    for (int r = 0; r < CB; r++) {
+      double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; k++) acc -= chol_rl(a[k], r) * y[k];
+      const double d = chol_rl(a[r], r);
+      y[r] = (r < nb) ? acc / d : acc;
+    }
+#pragma unroll
+    for (int r = 0; r < CB; r++) invout[(long)mat * CB * CB + r * CB + i] = y[r];
+  }
+}
+// L21 of the 16 rows from row0 (block column j0) as the transposed accumulator image lo = columns 0..15, hi = 16..31: lane (fx, fk),
+// register r holds L21[row0 + fx][fk + 4 r (+16)] - at once the A operand (own rows) and the B operand (rows of the next block) of
+// A[r, next block] -= L21[r] L21[next block]^T. k-steps run over the columns in the order 8 q + 2 fk + e: 16 contiguous bytes per load.
+__device__ __forceinline__ void chol_dprime(const double* __restrict__ Lb, int N, int j0, int row0, const double (*s_inv)[CB + 1],
+                                            int fx, int fk, d4& lo, d4& hi) {
+  double bk[8];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const d2 v = *reinterpret_cast<const d2*>(Lb + (long)(row0 + fx) * N + j0 + 8 * q + 2 * fk);
+    bk[2 * q] = v.x; bk[2 * q + 1] = v.y;
+  }
+  lo = d4{0.0, 0.0, 0.0, 0.0}; hi = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    const int kap = 8 * (ks >> 1) + 2 * fk + (ks & 1);
+    lo = __builtin_amdgcn_mfma_f64_16x16x4f64(s_inv[fx][kap], bk[ks], lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f64_16x16x4f64(s_inv[16 + fx][kap], bk[ks], hi, 0, 0, 0);
+  }
 }
 __global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags) {
   chol_diag_body(blockIdx.x, Lm, N, j0, nb, flags);
@@ -83,15 +119,14 @@ __global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, 
 // both are '4 consecutive doubles of a row'), accumulators start at C. Block column j0 itself got that update between the two launches
 // (the narrow GEMM in nd4_potrf), so the trailing update is off the critical path: per block diag + trsm + narrow instead of diag +
 // trsm + full update.
-typedef double d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags, int pj0, int ntc) {
-  const int mat = blockIdx.y, t = threadIdx.x;
-  if (blockIdx.x == 0) { if (t < 64) chol_diag_body(mat, Lm, N, j0, nb, flags); return; }
-  const int c1 = j0 + CB;                                   // first row / column of the part still lacking update pj0
-  const int tile = (int)blockIdx.x - 1, tr = tile / ntc, tc = tile % ntc;
+// one 64 x 32 tile of the trailing update A22 -= L21 L21^T of the block column at pj0, tiles counted from row / column c1.
+// (Sharing the tiles between the two launches of a step was tried: 1.63 -> 1.86 ms at 2048^2 - chol_diag_la is bound by its
+// one-wave chain of diagonal block + inverse, not by the tiles it carries.)
+__device__ __forceinline__ void chol_wide_tile(double* __restrict__ Lb, int N, int pj0, int c1, int tile, int ntc) {
+  const int t = threadIdx.x;
+  const int tr = tile / ntc, tc = tile % ntc;
   const int row0 = c1 + tr * 64, col0 = c1 + tc * 32;
   if (col0 > row0 + 63) return;                             // strictly above the diagonal
-  double* Lb = Lm + (long)mat * N * N;
   const int lane = t & 63, w = t >> 6, fx = lane & 15, fk = lane >> 4;
   const int rb = row0 + 16 * w;
   if (rb >= N) return;
@@ -125,6 +160,81 @@ __global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int
       const int row = rb + fk + 4 * r, col = col0 + 16 * j + fx;
       if (row < N && col < N) Lb[(long)row * N + col] = acc[j][r];
     }
+}
+
+__global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags, int pj0, int ntc,
+                                                     double* __restrict__ invout, double* __restrict__ ynext) {
+  const int mat = blockIdx.y, t = threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (t >= 64) return;
+    chol_diag_body(mat, Lm, N, j0, nb, flags, invout);
+    if (ynext != nullptr && j0 + 2 * CB <= N) {
+      // L21 of the NEXT block's 32 rows, for every wave of chol_trsm_narrow (which must not read those rows of A21 itself: their owner
+      // overwrites them in the same launch). One wave: the inverse goes through LDS into MFMA operand layout.
+      __shared__ double s_inv[CB][CB + 1];
+      __threadfence_block();
+      for (int e = t; e < CB * CB; e += 64) s_inv[e / CB][e % CB] = invout[(long)mat * CB * CB + e];
+      __syncthreads();
+      const int fx = t & 15, fk = t >> 4;
+      double* yo = ynext + (long)mat * 16 * 64;
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) {
+        d4 lo, hi;
+        chol_dprime(Lm + (long)mat * N * N, N, j0, j0 + CB + 16 * jt, s_inv, fx, fk, lo, hi);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { yo[((jt * 2 + 0) * 4 + r) * 64 + t] = lo[r]; yo[((jt * 2 + 1) * 4 + r) * 64 + t] = hi[r]; }
+      }
+    }
+    return;
+  }
+  chol_wide_tile(Lm + (long)mat * N * N, N, pj0, j0 + CB, (int)blockIdx.x - 1, ntc);
+}
+
+// rows below a full block (N a multiple of 32): L21 = A21 L_kk^-T on fp64 MFMA with the inverted diagonal block, AND the update of the
+// next block column, A[r, j1:j1+32] -= L21[r] L21[j1:j1+32]^T, in the same launch. A wave owns 16 rows. It forms D' = inv A_rows^T: the
+// accumulator of D' holds L21[row fx][fk + 4 r (+16)], which is both the A operand of the update (its own rows) and - computed
+// once more for the 32 rows of the next block, which every wave needs - the B operand: no LDS, no second launch, no dependence on
+// another workgroup. k-steps run over the columns in the order 8 q + 2 fk + e so that a lane reads 16 contiguous bytes per load.
+__global__ __launch_bounds__(256) void chol_trsm_narrow(double* __restrict__ Lm, int N, int j0, const double* __restrict__ invm,
+                                                         const double* __restrict__ ynext) {
+  __shared__ double s_inv[CB][CB + 1];
+  const int mat = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6, fx = lane & 15, fk = lane >> 4;
+  double* Lb = Lm + (long)mat * N * N;
+  for (int e = t; e < CB * CB; e += 256) s_inv[e / CB][e % CB] = invm[(long)mat * CB * CB + e];
+  __syncthreads();
+  const int j1 = j0 + CB;
+  const int r0 = j1 + ((int)blockIdx.x * 4 + w) * 16;
+  if (r0 >= N) return;
+  d4 x0, x1, y[2][2];
+  chol_dprime(Lb, N, j0, r0, s_inv, fx, fk, x0, x1);
+  {                                                      // the next block's rows: from chol_diag_la (their owner overwrites them here)
+    const double* yi = ynext + (long)mat * 16 * 64;
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { y[jt][0][r] = yi[((jt * 2 + 0) * 4 + r) * 64 + lane]; y[jt][1][r] = yi[((jt * 2 + 1) * 4 + r) * 64 + lane]; }
+  }
+  // the next block column first (reads the old A21 columns of nobody: only columns j1..), then L21 in place of A21
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) {
+    const int c0 = j1 + 16 * jt;
+    if (c0 > r0 + 15) continue;                          // strictly above the diagonal
+    d4 c;
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = Lb[(long)(r0 + fk + 4 * r) * N + c0 + fx];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0[kk], y[jt][0][kk], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[kk], y[jt][1][kk], c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) Lb[(long)(r0 + fk + 4 * r) * N + c0 + fx] = c[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    Lb[(long)(r0 + fx) * N + j0 + fk + 4 * r] = x0[r];
+    Lb[(long)(r0 + fx) * N + j0 + 16 + fk + 4 * r] = x1[r];
+  }
 }
 
 // rows r in [j0+nb, N): L[r, j0:j0+nb] = A[r, j0:j0+nb] L_kk^-T
@@ -252,6 +362,12 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
   hipLaunchKernelGGL(chol_copy_lower, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, S, L, N);
   static const bool la_off = getenv("ND4HIP_CHOL_NO_LOOKAHEAD") != nullptr;          // A/B switch
   const bool lookahead = !la_off && N >= 4 * CB && (long)batch * N <= 65536;
+  static const bool fused_off = getenv("ND4HIP_CHOL_NO_FUSED_TRSM") != nullptr;      // A/B switch
+  const bool fused_trsm = lookahead && !fused_off && (N % CB) == 0;                  // chol_trsm_narrow
+  Nd4WsScope scope(h);
+  double* inv = nullptr;
+  double* ynext = nullptr;
+  if (fused_trsm) { void* p = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * 2 * CB * CB, &p)); inv = static_cast<double*>(p); ynext = inv + (size_t)batch * CB * CB; }
   for (int j0 = 0, pj0 = -1; j0 < N; j0 += CB) {
     const int nb = N - j0 < CB ? N - j0 : CB;
     if (lookahead) {
@@ -259,12 +375,18 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
       const int rest = N - (j0 + CB);
       const int ntr = (pj0 >= 0 && rest > 0) ? (rest + 63) / 64 : 0, ntc = (pj0 >= 0 && rest > 0) ? (rest + 31) / 32 : 1;
       hipLaunchKernelGGL(chol_diag_la, dim3((unsigned)(1 + ntr * ntc), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb, flags,
-                         pj0 < 0 ? 0 : pj0, ntc);
+                         pj0 < 0 ? 0 : pj0, ntc, inv, ynext);
     } else {
       hipLaunchKernelGGL(chol_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, L, N, j0, nb, flags);
     }
     const int m2 = N - j0 - nb;
     if (m2 <= 0) break;
+    if (fused_trsm) {                                      // rows below the block and the next block column in one launch
+      hipLaunchKernelGGL(chol_trsm_narrow, dim3((unsigned)((m2 + 63) / 64), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, inv, ynext);
+      ND4_HIP(hipGetLastError());
+      pj0 = j0;
+      continue;
+    }
     hipLaunchKernelGGL(chol_trsm, dim3((unsigned)((m2 + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb);
     ND4_HIP(hipGetLastError());
     const int r0 = j0 + nb;
