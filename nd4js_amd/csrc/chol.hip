@@ -90,6 +90,49 @@ __device__ __forceinline__ void chol_diag_body(const int mat, double* __restrict
     for (int r = 0; r < CB; r++) invout[(long)mat * CB * CB + r * CB + i] = y[r];
   }
 }
+// (the LDL^T diagonal block: defined here because the look-ahead kernels below are shared with it)
+__device__ __forceinline__ void ldl_diag_body(const int mat, double* __restrict__ Lm, int N, int j0, int nb, double* __restrict__ invout = nullptr) {
+  double* A = Lm + (long)mat * N * N + (long)j0 * N + j0;
+  const int i = threadIdx.x;
+  double a[CB];
+#pragma unroll
+  for (int k = 0; k < CB; k++) a[k] = (i < nb && k <= i && k < nb) ? A[(long)i * N + k] : 0.0;
+  // as chol_diag_body: D_j and the unscaled column V = L[:,j] D_j (ldl.js:52) reach the other lanes as v_readlane values
+  auto column = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (j < nb) {
+      const double d = chol_rl(a[j], j);            // D_j (ldl.js:58-59 divides by LD[j,j])
+      const bool below = i > j && i < nb;
+      const double l = below ? a[j] / d : 0.0;
+#pragma unroll
+      for (int k = j + 1; k < CB; k++) a[k] -= l * chol_rl(a[j], k);      // V_k from lane k, still unscaled there
+      if (below) a[j] = l;
+    }
+  };
+#define ND4_CC(J) column(std::integral_constant<int, J>{});
+  ND4_CC(0) ND4_CC(1) ND4_CC(2) ND4_CC(3) ND4_CC(4) ND4_CC(5) ND4_CC(6) ND4_CC(7) ND4_CC(8) ND4_CC(9) ND4_CC(10) ND4_CC(11) ND4_CC(12) ND4_CC(13) ND4_CC(14) ND4_CC(15)
+  ND4_CC(16) ND4_CC(17) ND4_CC(18) ND4_CC(19) ND4_CC(20) ND4_CC(21) ND4_CC(22) ND4_CC(23) ND4_CC(24) ND4_CC(25) ND4_CC(26) ND4_CC(27) ND4_CC(28) ND4_CC(29) ND4_CC(30) ND4_CC(31)
+#undef ND4_CC
+  if (i < nb) {
+#pragma unroll
+    for (int k = 0; k < CB; k++)
+      if (k < nb) A[(long)i * N + k] = (k <= i) ? a[k] : 0.0;
+  }
+  if (invout != nullptr && i < CB) {                   // inverse of the UNIT lower block (no divisions), as in chol_diag_body
+    double y[CB];
+#pragma unroll
+    for (int r = 0; r < CB; r++) {
+      double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; k++) acc -= chol_rl(a[k], r) * y[k];
+      y[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < CB; r++) invout[(long)mat * CB * CB + r * CB + i] = y[r];
+  }
+}
+__global__ __launch_bounds__(64) void ldl_diag(double* __restrict__ Lm, int N, int j0, int nb) { ldl_diag_body(blockIdx.x, Lm, N, j0, nb); }
+
 // L21 of the 16 rows from row0 (block column j0) as the transposed accumulator image lo = columns 0..15, hi = 16..31: lane (fx, fk),
 // register r holds L21[row0 + fx][fk + 4 r (+16)] - at once the A operand (own rows) and the B operand (rows of the next block) of
 // A[r, next block] -= L21[r] L21[next block]^T. k-steps run over the columns in the order 8 q + 2 fk + e: 16 contiguous bytes per load.
@@ -122,6 +165,7 @@ __global__ __launch_bounds__(64) void chol_diag(double* __restrict__ Lm, int N, 
 // one 64 x 32 tile of the trailing update A22 -= L21 L21^T of the block column at pj0, tiles counted from row / column c1.
 // (Sharing the tiles between the two launches of a step was tried: 1.63 -> 1.86 ms at 2048^2 - chol_diag_la is bound by its
 // one-wave chain of diagonal block + inverse, not by the tiles it carries.)
+template <bool LDL>
 __device__ __forceinline__ void chol_wide_tile(double* __restrict__ Lb, int N, int pj0, int c1, int tile, int ntc) {
   const int t = threadIdx.x;
   const int tr = tile / ntc, tc = tile % ntc;
@@ -143,6 +187,7 @@ __device__ __forceinline__ void chol_wide_tile(double* __restrict__ Lb, int N, i
   for (int kk = 0; kk < 8; kk++) {
     const int ra = rb + fx;
     a[kk] = (ra < N) ? -Lb[(long)ra * N + pj0 + kk * 4 + fk] : 0.0;
+    if (LDL) a[kk] *= Lb[(long)(pj0 + kk * 4 + fk) * N + pj0 + kk * 4 + fk];       // (L21 D11) L21^T: column c of L21 times d_c
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int cr = col0 + 16 * j + fx;                    // row of L that is column cr of L^T
@@ -162,12 +207,13 @@ __device__ __forceinline__ void chol_wide_tile(double* __restrict__ Lb, int N, i
     }
 }
 
+template <bool LDL>
 __global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int N, int j0, int nb, int* __restrict__ flags, int pj0, int ntc,
                                                      double* __restrict__ invout, double* __restrict__ ynext) {
   const int mat = blockIdx.y, t = threadIdx.x;
   if (blockIdx.x == 0) {
     if (t >= 64) return;
-    chol_diag_body(mat, Lm, N, j0, nb, flags, invout);
+    if (LDL) ldl_diag_body(mat, Lm, N, j0, nb, invout); else chol_diag_body(mat, Lm, N, j0, nb, flags, invout);
     if (ynext != nullptr && j0 + 2 * CB <= N) {
       // L21 of the NEXT block's 32 rows, for every wave of chol_trsm_narrow (which must not read those rows of A21 itself: their owner
       // overwrites them in the same launch). One wave: the inverse goes through LDS into MFMA operand layout.
@@ -181,13 +227,21 @@ __global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int
       for (int jt = 0; jt < 2; jt++) {
         d4 lo, hi;
         chol_dprime(Lm + (long)mat * N * N, N, j0, j0 + CB + 16 * jt, s_inv, fx, fk, lo, hi);
+        if (LDL) {                                       // image of W = L21 D11 -> image of L21: column fk + 4 r (+16) divided by its d
+          const double* Ld = Lm + (long)mat * N * N;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            lo[r] = lo[r] / Ld[(long)(j0 + fk + 4 * r) * N + j0 + fk + 4 * r];
+            hi[r] = hi[r] / Ld[(long)(j0 + 16 + fk + 4 * r) * N + j0 + 16 + fk + 4 * r];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) { yo[((jt * 2 + 0) * 4 + r) * 64 + t] = lo[r]; yo[((jt * 2 + 1) * 4 + r) * 64 + t] = hi[r]; }
       }
     }
     return;
   }
-  chol_wide_tile(Lm + (long)mat * N * N, N, pj0, j0 + CB, (int)blockIdx.x - 1, ntc);
+  chol_wide_tile<LDL>(Lm + (long)mat * N * N, N, pj0, j0 + CB, (int)blockIdx.x - 1, ntc);
 }
 
 // rows below a full block (N a multiple of 32): L21 = A21 L_kk^-T on fp64 MFMA with the inverted diagonal block, AND the update of the
@@ -195,6 +249,7 @@ __global__ __launch_bounds__(256) void chol_diag_la(double* __restrict__ Lm, int
 // accumulator of D' holds L21[row fx][fk + 4 r (+16)], which is both the A operand of the update (its own rows) and - computed
 // once more for the 32 rows of the next block, which every wave needs - the B operand: no LDS, no second launch, no dependence on
 // another workgroup. k-steps run over the columns in the order 8 q + 2 fk + e so that a lane reads 16 contiguous bytes per load.
+template <bool LDL>
 __global__ __launch_bounds__(256) void chol_trsm_narrow(double* __restrict__ Lm, int N, int j0, const double* __restrict__ invm,
                                                          const double* __restrict__ ynext) {
   __shared__ double s_inv[CB][CB + 1];
@@ -232,8 +287,11 @@ __global__ __launch_bounds__(256) void chol_trsm_narrow(double* __restrict__ Lm,
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    Lb[(long)(r0 + fx) * N + j0 + fk + 4 * r] = x0[r];
-    Lb[(long)(r0 + fx) * N + j0 + 16 + fk + 4 * r] = x1[r];
+    // LDL^T: x is the image of W = L21 D11 (what the update above used as its A operand); L21 = W / d, true division like ldl.js:58-59
+    const double d0 = LDL ? Lb[(long)(j0 + fk + 4 * r) * N + j0 + fk + 4 * r] : 1.0;
+    const double d1 = LDL ? Lb[(long)(j0 + 16 + fk + 4 * r) * N + j0 + 16 + fk + 4 * r] : 1.0;
+    Lb[(long)(r0 + fx) * N + j0 + fk + 4 * r] = LDL ? x0[r] / d0 : x0[r];
+    Lb[(long)(r0 + fx) * N + j0 + 16 + fk + 4 * r] = LDL ? x1[r] / d1 : x1[r];
   }
 }
 
@@ -280,35 +338,6 @@ __global__ __launch_bounds__(256) void chol_trsm(double* __restrict__ Lm, int N,
 }
 
 // ---- LDL^T ----
-__global__ __launch_bounds__(64) void ldl_diag(double* __restrict__ Lm, int N, int j0, int nb) {
-  double* A = Lm + (long)blockIdx.x * N * N + (long)j0 * N + j0;
-  const int i = threadIdx.x;
-  double a[CB];
-#pragma unroll
-  for (int k = 0; k < CB; k++) a[k] = (i < nb && k <= i && k < nb) ? A[(long)i * N + k] : 0.0;
-  // as chol_diag_body: D_j and the unscaled column V = L[:,j] D_j (ldl.js:52) reach the other lanes as v_readlane values
-  auto column = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if (j < nb) {
-      const double d = chol_rl(a[j], j);            // D_j (ldl.js:58-59 divides by LD[j,j])
-      const bool below = i > j && i < nb;
-      const double l = below ? a[j] / d : 0.0;
-#pragma unroll
-      for (int k = j + 1; k < CB; k++) a[k] -= l * chol_rl(a[j], k);      // V_k from lane k, still unscaled there
-      if (below) a[j] = l;
-    }
-  };
-#define ND4_CC(J) column(std::integral_constant<int, J>{});
-  ND4_CC(0) ND4_CC(1) ND4_CC(2) ND4_CC(3) ND4_CC(4) ND4_CC(5) ND4_CC(6) ND4_CC(7) ND4_CC(8) ND4_CC(9) ND4_CC(10) ND4_CC(11) ND4_CC(12) ND4_CC(13) ND4_CC(14) ND4_CC(15)
-  ND4_CC(16) ND4_CC(17) ND4_CC(18) ND4_CC(19) ND4_CC(20) ND4_CC(21) ND4_CC(22) ND4_CC(23) ND4_CC(24) ND4_CC(25) ND4_CC(26) ND4_CC(27) ND4_CC(28) ND4_CC(29) ND4_CC(30) ND4_CC(31)
-#undef ND4_CC
-  if (i < nb) {
-#pragma unroll
-    for (int k = 0; k < CB; k++)
-      if (k < nb) A[(long)i * N + k] = (k <= i) ? a[k] : 0.0;
-  }
-}
-
 // rows r in [j0+nb, N): y = A[r, j0:j0+nb] L11^-T (unit lower), W[r - r0, :] = y, L[r, j0:j0+nb] = y / D
 __global__ __launch_bounds__(256) void ldl_trsm(double* __restrict__ Lm, int N, int j0, int nb, double* __restrict__ Wm, long sW) {
   double* Lb = Lm + (long)blockIdx.y * N * N;
@@ -374,7 +403,7 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
       // block column j0 is complete (narrow update below); the columns from j0 + CB on still lack the update of block column pj0
       const int rest = N - (j0 + CB);
       const int ntr = (pj0 >= 0 && rest > 0) ? (rest + 63) / 64 : 0, ntc = (pj0 >= 0 && rest > 0) ? (rest + 31) / 32 : 1;
-      hipLaunchKernelGGL(chol_diag_la, dim3((unsigned)(1 + ntr * ntc), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb, flags,
+      hipLaunchKernelGGL(chol_diag_la<false>, dim3((unsigned)(1 + ntr * ntc), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, nb, flags,
                          pj0 < 0 ? 0 : pj0, ntc, inv, ynext);
     } else {
       hipLaunchKernelGGL(chol_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, L, N, j0, nb, flags);
@@ -382,7 +411,7 @@ int nd4_potrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, d
     const int m2 = N - j0 - nb;
     if (m2 <= 0) break;
     if (fused_trsm) {                                      // rows below the block and the next block column in one launch
-      hipLaunchKernelGGL(chol_trsm_narrow, dim3((unsigned)((m2 + 63) / 64), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, inv, ynext);
+      hipLaunchKernelGGL(chol_trsm_narrow<false>, dim3((unsigned)((m2 + 63) / 64), (unsigned)batch), dim3(256), 0, h->stream, L, N, j0, inv, ynext);
       ND4_HIP(hipGetLastError());
       pj0 = j0;
       continue;
@@ -418,6 +447,27 @@ int nd4_ldltrf(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* S, 
   double* W = static_cast<double*>(p);
   const unsigned gy = (unsigned)(N < 1024 ? N : 1024);
   hipLaunchKernelGGL(chol_copy_lower, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, S, LD, N);
+  static const bool la_off = getenv("ND4HIP_CHOL_NO_LOOKAHEAD") != nullptr || getenv("ND4HIP_CHOL_NO_FUSED_TRSM") != nullptr;   // A/B switches
+  if (!la_off && N >= 4 * CB && (N % CB) == 0 && (long)batch * N <= 65536) {
+    // the Cholesky look-ahead step with D in it (chol_diag_la<true> / chol_trsm_narrow<true>): see nd4_potrf
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * 2 * CB * CB, &q));
+    double* inv = static_cast<double*>(q);
+    double* ynext = inv + (size_t)batch * CB * CB;
+    for (int j0 = 0, pj0 = -1; j0 < N; j0 += CB) {
+      const int rest = N - (j0 + CB);
+      const int ntr = (pj0 >= 0 && rest > 0) ? (rest + 63) / 64 : 0, ntc = (pj0 >= 0 && rest > 0) ? (rest + 31) / 32 : 1;
+      hipLaunchKernelGGL(chol_diag_la<true>, dim3((unsigned)(1 + ntr * ntc), (unsigned)batch), dim3(256), 0, h->stream, LD, N, j0, CB,
+                         (int*)nullptr, pj0 < 0 ? 0 : pj0, ntc, inv, ynext);
+      const int m2 = N - j0 - CB;
+      if (m2 <= 0) break;
+      hipLaunchKernelGGL(chol_trsm_narrow<true>, dim3((unsigned)((m2 + 63) / 64), (unsigned)batch), dim3(256), 0, h->stream, LD, N, j0, inv, ynext);
+      pj0 = j0;
+    }
+    hipLaunchKernelGGL(chol_finish, dim3((unsigned)((N + 255) / 256), gy, (unsigned)batch), dim3(256), 0, h->stream, LD, N);
+    ND4_HIP(hipGetLastError());
+    return 0;
+  }
   for (int j0 = 0; j0 < N; j0 += CB) {
     const int nb = N - j0 < CB ? N - j0 : CB;
     hipLaunchKernelGGL(ldl_diag, dim3((unsigned)batch), dim3(64), 0, h->stream, LD, N, j0, nb);
