@@ -33,7 +33,7 @@ def dims(lo, hi, mult=None):
 for it in range(cases):
     # ---- QR (look-ahead, Q^T accumulator, wide / tall / batched)
     b = int(rs.choice([1, 1, 1, 2, 3, 5]))
-    M, N = dims(60, 700, 16), dims(1, 700, 16)
+    M, N = dims(60, int(os.environ.get("FUZZ_MAX", 700)), 16), dims(1, int(os.environ.get("FUZZ_MAX", 700)), 16)
     a = rs.standard_normal((b, M, N)) if b > 1 else rs.standard_normal((M, N))
     q, r = la.qr_decomp(a)
     L = min(M, N)
