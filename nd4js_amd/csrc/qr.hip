@@ -425,10 +425,10 @@ __device__ __forceinline__ void qr_colblock_update(double* __restrict__ s_X, dou
     const int i = t / 16, j = t % 16;
     if (trans) {
 #pragma unroll
-      for (int l = 0; l < NB; l++) if (l <= i) wv += s_Tm[l][i] * s_Xs[l * 16 + j];
+      for (int l = 0; l < NB; l++) wv += s_Tm[l][i] * s_Xs[l * 16 + j];
     } else {
 #pragma unroll
-      for (int l = 0; l < NB; l++) if (l >= i) wv += s_Tm[i][l] * s_Xs[l * 16 + j];
+      for (int l = 0; l < NB; l++) wv += s_Tm[i][l] * s_Xs[l * 16 + j];
     }
   }
   __syncthreads();
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void qr_narrow_x(const double* __restrict__ Wm
 __global__ __launch_bounds__(256) void qr_narrow_apply(double* __restrict__ Wm, int M, int N, long ld, long strideW,
                                                         const double* __restrict__ Vall, long ldv, long strideV,
                                                         const double* __restrict__ Tall, long strideT, int pj0, int c0,
-                                                        const double* __restrict__ Xp, long strideXp) {
+                                                        const double* __restrict__ Xp, long strideXp, int nparts) {
   __shared__ double s_Xs[256];
   __shared__ double s_Tm[NB][NB + 1];
   const int mat = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
@@ -523,14 +523,15 @@ __global__ __launch_bounds__(256) void qr_narrow_apply(double* __restrict__ Wm, 
   }
   s_Tm[t / NB][t % NB] = Tall[mat * strideT + (long)(pj0 / NB) * NB * NB + t];
   double x = 0.0;
-  for (int g = 0; g < (int)gridDim.x; g++) x += Xp[mat * strideXp + (long)g * 256 + t];     // fixed order, the same in every workgroup
+  if (nparts <= 0) nparts = (int)gridDim.x;                                                    // qr_narrow_x: one partial per workgroup
+  for (int g = 0; g < nparts; g++) x += Xp[mat * strideXp + (long)g * 256 + t];               // fixed order, the same in every workgroup
   s_Xs[t] = x;
   __syncthreads();
   double wv = 0.0;
   {
     const int i = t / 16, j = t % 16;
 #pragma unroll
-    for (int l = 0; l < NB; l++) if (l <= i) wv += s_Tm[l][i] * s_Xs[l * 16 + j];            // T^T X
+    for (int l = 0; l < NB; l++) wv += s_Tm[l][i] * s_Xs[l * 16 + j];            // T^T X (T: full 16 x 16, see qrh_reconstruct)
   }
   __syncthreads();
   s_Xs[t] = -wv;
@@ -591,6 +592,536 @@ __global__ __launch_bounds__(NT) void qr_update_blocks(double* __restrict__ Cm, 
   const int nc = ncols - c0 < NB ? ncols - c0 : NB;
   qr_colblock_update<NT>(s_X, s_Tm, Tall + mat * strideT + (long)(pj0 / NB) * NB * NB, 1,
                          Vall + mat * strideV + (long)pj0 * ldv + pj0, ldv, Cm + mat * strideC + (long)pj0 * ld + c0, ld, M - pj0, nc);
+}
+
+// =====================================================================================================================
+// Multi-workgroup panel (round 3): CholeskyQR2 + a Householder-type representation of its orthonormal factor.
+//
+// qr_panel_row<R> is ONE workgroup walking a chain of 16 dependent column steps (reduce over all rows, barrier, reflector
+// scalars, update): 27-48 us per panel on one CU, 79 % of a 2048^2 factorisation. Here the panel's ROWS are split over
+// workgroups of 512 rows and every step that touches all rows is an fp64-MFMA pass whose only cross-workgroup coupling is the
+// sum of 16 x 16 partial matrices, taken across a kernel boundary (the cheap grid barrier of this chip, ~1.5 us):
+//   A  C <- (I - V T^T V^T) C for the panel's own 16 columns (the previous reflector, X = V^T C summed from the partials phase C
+//      left behind), then partial Gram matrices G = C^T C of the updated rows;
+//   B  every workgroup: R1 = chol(G) and R1^-1 (one wave, Gaussian elimination on [G | I], columns across lanes, pivot column
+//      broadcast by v_readlane), Q1 = C R1^-1 in place, partial Gram matrices of Q1;
+//   C  every workgroup: R2 = chol(Q1^T Q1) = I + F from two fixed-point steps of F = triu(E - F^T F) (E = Q1^T Q1 - I is
+//      O(cond^2 eps): no chain; the elimination chain only when max|E| > 1e-5), Q = Q1 R2^-1 (CholeskyQR2: orthonormal to
+//      O(eps)), R = S R2 R1, and the orthogonal completion of Q in compact form (Yamamoto's representation with the sign
+//      choice of Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik, "Reconstructing Householder vectors from tall-skinny
+//      QR", 2014):   H = I - W K W^T,  W = Q - [S; 0],  K = -S (Q_top - S)^-T,  S = diag(+-1) = -sign of the pivots of the
+//      Gauss-Jordan elimination of Q_top - S (every pivot has magnitude >= 1).  H is orthogonal (K^-1 + K^-T = W^T W), its
+//      first 16 columns are Q S, so H^T [panel] = [S R; 0]: (W, K, S R) is a (V, T, R) triple for everything downstream — V's
+//      top block is full instead of unit lower triangular and T is a full 16 x 16 matrix, which is why every consumer of T
+//      uses all 256 entries. The same launch leaves the partials of X = V^T C for the NEXT panel's columns.
+// Three short launches per panel instead of one long one. The previous reflector's work on the other column blocks (trailing
+// columns of W, Q^T) rides along in two phases, split over 512-row chunks like the panel itself: partial X = V^T C in launch A,
+// C -= V (T^T X) in launches B (W) and C (Q^T). Panels the Gram route must not take — (nearly) dependent columns (a Cholesky
+// pivot below HR_PIVOT_THR of its diagonal entry), columns that are exactly zero below the top block (triangular / banded input,
+// where the reference skips rotations: qr.js:60,63) or non-finite data — are flagged by phase B and factorised by
+// qr_panel_row_body in workgroup 0 of phase C: same result as before, at the old speed.
+constexpr double HR_PIVOT_THR = 1e-5;
+constexpr double HR_SERIES_MAX = 1e-5;
+constexpr int HR_MIN_ROWS = 64;
+
+struct QrhP {
+  double* Wm; int M, N; long ld, strideW;
+  double* Vall; long ldv, strideV;
+  double* Tall; long strideT;
+  double* taus; long strideTau;
+  double* Xp; long strideXp;        // partials of X = V^T C on the next panel's columns: [part][256]
+  double* Gp; long strideGp;        // slot 0: Gram of the top 16 rows; slots 1..: partial Gram matrices of the rows below
+  double* G2p; long strideG2;       // partial Gram matrices of Q1
+  double* R1; int* flag;            // per matrix: R1 (16 x 16), fall-back flag
+  double* QT; long strideQT;
+  double* Xs; long strideXs;        // side work: partials of X per (column block, row chunk): [cb][rc][256]
+  int j0;                           // first row / column of the panel
+  int pj0;                          // previous panel (-1: none): its reflector is what the side blocks and phase A apply
+  int nxp;                          // partials of X to sum in phase A
+  int nrow;                         // row workgroups of this launch
+  int ngp;                          // Gram partials to sum (phase B: phase A's row workgroups; phase C: phase B's)
+  int wide0, nwide, nq, nrc;        // side work: nwide column blocks of W from wide0 on, then nq column blocks of Q^T, nrc row chunks each
+  int cb0;                          // first column block of this launch's side work (workgroup -> block cb0 + i / nrc, chunk i % nrc)
+};
+
+template <int K, int I>
+__device__ __forceinline__ void qrh_ge_row(double (&g)[16], double gk) {
+  if constexpr (I > K) g[I] = fma(-nd4dpp::rl_d(g[I], K), gk, g[I]);
+}
+template <int K, int... I>
+__device__ __forceinline__ void qrh_ge_rows(double (&g)[16], double gk, std::integer_sequence<int, I...>) { (qrh_ge_row<K, I>(g, gk), ...); }
+template <int K>
+__device__ __forceinline__ void qrh_ge_step(double (&g)[16], double (&d)[16]) {
+  const double pk = nd4dpp::rl_d(g[K], K);
+  d[K] = pk;
+  qrh_ge_rows<K>(g, g[K] * nd4dpp::fast_rcp(pk), std::make_integer_sequence<int, 16>{});     // row i -= G[i][K] * (row K / pivot)
+}
+template <int... K>
+__device__ __forceinline__ void qrh_ge_all(double (&g)[16], double (&d)[16], std::integer_sequence<int, K...>) { (qrh_ge_step<K>(g, d), ...); }
+
+// One wave. s_G: symmetric positive definite 16 x 16. Out: s_R = chol(G)^T (upper, G = R^T R), s_Ri = R^-1 (upper).
+// Lanes 0..15 hold the columns of G, lanes 16..31 the columns of I; elimination without pivoting leaves U = D L^T and L^-1,
+// R = D^-1/2 U, R^-1 = (D^-1/2 L^-1)^T. Returns true when every pivot is positive and >= thr * its diagonal entry.
+__device__ __forceinline__ bool qrh_chol16(const double* __restrict__ s_G, double* __restrict__ s_R, double* __restrict__ s_Ri, double thr) {
+  const int lane = threadIdx.x & 63;
+  double g[16], d[16], d0[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) g[i] = lane < 16 ? s_G[i * 16 + lane] : ((lane - 16) == i ? 1.0 : 0.0);
+#define ND4_D0(K) d0[K] = nd4dpp::rl_d(g[K], K);
+  ND4_D0(0) ND4_D0(1) ND4_D0(2) ND4_D0(3) ND4_D0(4) ND4_D0(5) ND4_D0(6) ND4_D0(7)
+  ND4_D0(8) ND4_D0(9) ND4_D0(10) ND4_D0(11) ND4_D0(12) ND4_D0(13) ND4_D0(14) ND4_D0(15)
+#undef ND4_D0
+  qrh_ge_all(g, d, std::make_integer_sequence<int, 16>{});
+  bool ok = true;
+  double rs[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    ok = ok && (d[k] > 0.0) && (d[k] >= thr * d0[k]) && (d0[k] < DBL_MAX);
+    rs[k] = nd4dpp::fast_rsqrt(d[k]);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) s_R[i * 16 + lane] = (i <= lane) ? g[i] * rs[i] : 0.0;
+  } else if (lane < 32) {
+    const int c = lane - 16;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s_Ri[c * 16 + r] = (r >= c) ? g[r] * rs[r] : 0.0;
+  }
+  return ok;
+}
+
+template <int K, int I>
+__device__ __forceinline__ void qrh_gj_row(double (&g)[16], double gk) {
+  if constexpr (I != K) g[I] = fma(-nd4dpp::rl_d(g[I], K), gk, g[I]);
+}
+template <int K, int... I>
+__device__ __forceinline__ void qrh_gj_rows(double (&g)[16], double gk, std::integer_sequence<int, I...>) { (qrh_gj_row<K, I>(g, gk), ...); }
+template <int K>
+__device__ __forceinline__ void qrh_gj_step(double (&g)[16], double (&sg)[16], int lane) {
+  const double p = nd4dpp::rl_d(g[K], K);
+  const double s = (p >= 0.0) ? -1.0 : 1.0;            // the pivot p - s has magnitude >= 1
+  sg[K] = s;
+  if (lane == K) g[K] -= s;
+  const double gk = g[K] * nd4dpp::fast_rcp(p - s);    // row K of [B | I], scaled
+  qrh_gj_rows<K>(g, gk, std::make_integer_sequence<int, 16>{});
+  g[K] = gk;
+}
+template <int... K>
+__device__ __forceinline__ void qrh_gj_all(double (&g)[16], double (&sg)[16], int lane, std::integer_sequence<int, K...>) { (qrh_gj_step<K>(g, sg, lane), ...); }
+
+// One wave. s_Z: top 16 x 16 block of the orthonormal Q. Gauss-Jordan elimination without pivoting of [Z - S | I] with
+// S_k = -sign(pivot) chosen on the way (lanes 0..15: columns of Z, lanes 16..31: columns of I -> B^-1, B = Z - S).
+// Out: s_S (signs) and s_K = K = -S B^-T (K[c][r] = -S_c B^-1[r][c]: lane 16 + c writes row c).
+__device__ __forceinline__ void qrh_gj16(const double* __restrict__ s_Z, double* __restrict__ s_K, double* __restrict__ s_S) {
+  const int lane = threadIdx.x & 63;
+  double g[16], sg[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) g[i] = lane < 16 ? s_Z[i * 16 + lane] : ((lane - 16) == i ? 1.0 : 0.0);
+  qrh_gj_all(g, sg, lane, std::make_integer_sequence<int, 16>{});
+  if (lane >= 16 && lane < 32) {
+    const int c = lane - 16;
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (c == k) sc = sg[k];
+#pragma unroll
+    for (int r = 0; r < 16; r++) s_K[c * 16 + r] = -sc * g[r];
+    s_S[c] = sc;
+  }
+}
+
+constexpr int QRH_LDS = 8 * 256 + 256 + NB * (NB + 1) + 16;      // doubles: what qr_colblock_update<512> needs; the phases carve the same buffer
+
+// fixed-order sum of the eight waves' 16 x 16 accumulators -> dst[256] (global)
+__device__ __forceinline__ void qrh_reduce_store(double* __restrict__ s_part, const d4& a0, const d4& a1, double* __restrict__ dst) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_part[wave * 256 + (fk + 4 * r) * 16 + fx] = a0[r] + a1[r];
+  __syncthreads();
+  if (t < 256) {
+    double x = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) x += s_part[w * 256 + t];
+    dst[t] = x;
+  }
+}
+
+// The wave's 64 rows [rb, rb + 64) of a 16-column block: C <- C - V (T^T X), X = the sum of nx partials (256 doubles apart, fixed
+// order, the same in every workgroup). Vcol / Ccol point at (row 0, first column) of the reflector / the block. On return c holds
+// the updated tile in accumulator layout (c[q][r]: row rb + 16 q + fk + 4 r, column fx; rows outside [0, M) are zero).
+// s_w: 512 doubles of LDS. Every thread of the workgroup must call it.
+__device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const double* __restrict__ Xsrc, int nx, const double* __restrict__ Tg,
+                                               const double* __restrict__ Vcol, long ldv, double* __restrict__ Ccol, long ldc, int nc,
+                                               int rb, int M, d4 (&c)[4]) {
+  const int t = threadIdx.x, lane = t & 63, fx = lane & 15, fk = lane >> 4;
+  const bool cok = fx < nc;
+  double av[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rb + q * 16 + fk + 4 * r;
+      c[q][r] = (rc >= 0 && rc < M && cok) ? Ccol[(long)rc * ldc + fx] : 0.0;
+    }
+    const int ra = rb + q * 16 + fx;
+    if (ra >= 0 && ra < M) {                                           // 32 contiguous bytes per lane: k-step kk <-> column 4 fk + kk
+      const double2 v0 = *reinterpret_cast<const double2*>(Vcol + (long)ra * ldv + 4 * fk);
+      const double2 v1 = *reinterpret_cast<const double2*>(Vcol + (long)ra * ldv + 4 * fk + 2);
+      av[q][0] = v0.x; av[q][1] = v0.y; av[q][2] = v1.x; av[q][3] = v1.y;
+    } else { av[q][0] = av[q][1] = av[q][2] = av[q][3] = 0.0; }
+  }
+  double* s_X = s_w;
+  double* s_Tm = s_w + 256;
+  if (t < 256) {
+    double x = 0.0;
+    for (int p = 0; p < nx; p++) x += Xsrc[(long)p * 256 + t];
+    s_X[t] = x;
+    s_Tm[t] = Tg[t];
+  }
+  __syncthreads();
+  double wv = 0.0;
+  if (t < 256) {
+    const int i = t / 16, j = t % 16;
+#pragma unroll
+    for (int l = 0; l < NB; l++) wv += s_Tm[l * 16 + i] * s_X[l * 16 + j];                   // T^T X, T a full 16 x 16 matrix
+  }
+  __syncthreads();
+  if (t < 256) s_X[t] = -wv;
+  __syncthreads();
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_X[(4 * fk + kk) * 16 + fx];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rb + q * 16 + fk + 4 * r;
+      if (rc >= 0 && rc < M && cok) Ccol[(long)rc * ldc + fx] = c[q][r];
+    }
+  }
+}
+
+// ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks, in two phases ----
+struct QrhSide { double* C; long ldc; int c0, nc, cb, rc; };
+__device__ __forceinline__ QrhSide qrh_side_of(const QrhP& P, int mat, int i) {
+  QrhSide s;
+  s.cb = P.cb0 + i / P.nrc; s.rc = i % P.nrc;
+  if (s.cb < P.nwide) { s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB; s.nc = P.N - s.c0 < NB ? P.N - s.c0 : NB; }
+  else                { s.C = P.QT + mat * P.strideQT; s.ldc = P.M; s.c0 = (s.cb - P.nwide) * NB; s.nc = P.M - s.c0 < NB ? P.M - s.c0 : NB; }
+  return s;
+}
+// partial X = V^T C over one 512-row chunk of one column block
+__device__ __forceinline__ void qrh_side_x(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
+  const QrhSide s = qrh_side_of(P, mat, i);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int rb = P.pj0 + s.rc * 512 + wave * 64;
+  const double* V = P.Vall + mat * P.strideV + P.pj0;
+  const bool cok = fx < s.nc;
+  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
+  double v[16], c[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) {                                       // 16 slabs of 4 rows: both operands in the same (row fk, column fx) layout
+    const int r = rb + 4 * u + fk;
+    v[u] = r < P.M ? V[(long)r * P.ldv + fx] : 0.0;
+    c[u] = (r < P.M && cok) ? s.C[(long)r * s.ldc + s.c0 + fx] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 16; u += 2) {
+    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c[u], x0, 0, 0, 0);
+    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c[u + 1], x1, 0, 0, 0);
+  }
+  qrh_reduce_store(s_buf, x0, x1, P.Xs + mat * P.strideXs + ((long)s.cb * P.nrc + s.rc) * 256);
+}
+// C -= V (T^T X) on one 512-row chunk of one column block
+__device__ __forceinline__ void qrh_side_apply(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
+  const QrhSide s = qrh_side_of(P, mat, i);
+  const int wave = threadIdx.x >> 6;
+  d4 c[4];
+  qrh_apply_rows(s_buf, P.Xs + mat * P.strideXs + (long)s.cb * P.nrc * 256, P.nrc, P.Tall + mat * P.strideT + (long)(P.pj0 / NB) * NB * NB,
+                 P.Vall + mat * P.strideV + P.pj0, P.ldv, s.C + s.c0, s.ldc, s.nc, P.pj0 + s.rc * 512 + wave * 64, P.M, c);
+}
+
+// ---- phase A: the previous reflector on the panel's own columns (rows from j0 - 16), then the partial Gram matrices ----
+__global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
+  __shared__ double s_buf[QRH_LDS];
+  const int mat = blockIdx.y;
+  if ((int)blockIdx.x >= P.nrow) { qrh_side_x(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  double* A = P.Wm + mat * P.strideW;
+  const int j0 = P.j0, ub = j0 - NB, M = P.M;
+  const int rb = ub + (g * 8 + wave) * 64;
+  d4 c[4];
+  if (P.pj0 >= 0) {
+    qrh_apply_rows(s_buf, P.Xp + mat * P.strideXp, P.nxp, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                   P.Vall + mat * P.strideV + ub, P.ldv, A + j0, P.ld, NB, rb, M, c);
+    __syncthreads();                                                  // s_buf is reused below
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        c[q][r] = (rc >= 0 && rc < M) ? A[(long)rc * P.ld + j0 + fx] : 0.0;
+      }
+    }
+  }
+  // Gram matrices: the accumulator image of a 16-row tile is four 4-row slabs in operand layout (A and B operand alike)
+  d4 g0 = d4{0.0, 0.0, 0.0, 0.0}, g1 = g0, gt = g0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ti = (g * 8 + wave) * 4 + q;                            // tile 0: the 16 rows above the panel, tile 1: its top block
+    if (ti == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) gt = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][r], c[q][r], gt, 0, 0, 0);
+    } else if (ti >= 2) {
+      g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][0], c[q][0], g0, 0, 0, 0);
+      g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][1], c[q][1], g1, 0, 0, 0);
+      g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][2], c[q][2], g0, 0, 0, 0);
+      g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][3], c[q][3], g1, 0, 0, 0);
+    }
+  }
+  if (g == 0 && wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) P.Gp[mat * P.strideGp + (fk + 4 * r) * 16 + fx] = gt[r];
+  }
+  qrh_reduce_store(s_buf, g0, g1, P.Gp + mat * P.strideGp + (long)(1 + g) * 256);
+}
+
+// the wave's 64 rows of the panel's 16 columns as MFMA A operands (k-step kk <-> column 4 fk + kk: 32 contiguous bytes per lane)
+__device__ __forceinline__ void qrh_load_rows(const double* __restrict__ A, long ld, int j0, int rb, int M, double (&a)[4][4]) {
+  const int lane = threadIdx.x & 63, fx = lane & 15, fk = lane >> 4;
+  const bool vec = (ld & 1) == 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = rb + q * 16 + fx;
+    const double* src = A + (long)ra * ld + j0 + 4 * fk;
+    if (ra < M) {
+      if (vec) {
+        const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
+        a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
+      } else { a[q][0] = src[0]; a[q][1] = src[1]; a[q][2] = src[2]; a[q][3] = src[3]; }
+    } else { a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0.0; }
+  }
+}
+
+// ---- phase B: R1 = chol(G), Q1 = C R1^-1 in place, partial Gram matrices of Q1; decides the fall-back ----
+__global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
+  __shared__ double s_buf[QRH_LDS];
+  __shared__ double s_G[256], s_R[256], s_Ri[256], s_db[16];
+  __shared__ int s_flag;
+  const int mat = blockIdx.y;
+  if ((int)blockIdx.x >= P.nrow) { qrh_side_apply(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  double* A = P.Wm + mat * P.strideW;
+  const int j0 = P.j0, M = P.M;
+  const long ld = P.ld;
+  const int rb = j0 + (g * 8 + wave) * 64;
+  double a[4][4];
+  qrh_load_rows(A, ld, j0, rb, M, a);
+  if (t < 256) {
+    double gb = 0.0;
+    for (int p = 0; p < P.ngp; p++) gb += P.Gp[mat * P.strideGp + (long)(1 + p) * 256 + t];
+    s_G[t] = gb + P.Gp[mat * P.strideGp + t];
+    if (t % 17 == 0) s_db[t / 17] = gb;                               // column sums of squares below the top block
+  }
+  __syncthreads();
+  if (wave == 0) {
+    bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
+#pragma unroll
+    for (int k = 0; k < 16; k++) ok = ok && (s_db[k] > 0.0);
+    if (lane == 0) s_flag = ok ? 0 : 1;
+  }
+  __syncthreads();
+  const int flag = s_flag;
+  if (g == 0) {
+    if (t == 0) P.flag[mat] = flag;
+    if (t < 256) P.R1[(long)mat * 256 + t] = s_R[t];
+  }
+  if (flag) return;
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_Ri[(4 * fk + kk) * 16 + fx];
+  d4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], bw[kk], acc[q], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rb + q * 16 + fk + 4 * r;
+      if (rc < M) A[(long)rc * ld + j0 + fx] = acc[q][r];
+    }
+  }
+  d4 g0 = d4{0.0, 0.0, 0.0, 0.0}, g1 = g0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][0], acc[q][0], g0, 0, 0, 0);
+    g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][1], acc[q][1], g1, 0, 0, 0);
+    g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][2], acc[q][2], g0, 0, 0, 0);
+    g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][3], acc[q][3], g1, 0, 0, 0);
+  }
+  qrh_reduce_store(s_buf, g0, g1, P.G2p + mat * P.strideG2 + (long)g * 256);
+}
+
+// X = V^T C over all m rows by the eight waves of one workgroup -> dst[256] (the fall-back panel's share of phase C)
+__device__ __forceinline__ void qrh_x_full(double* __restrict__ s_part, const double* __restrict__ V, long ldv, const double* __restrict__ C, long ldc,
+                                           int m, int nc, double* __restrict__ dst) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int rpw = ((m + 8 * 16 - 1) / (8 * 16)) * 16;
+  const int r0 = wave * rpw, r1 = (r0 + rpw < m) ? r0 + rpw : m;
+  const bool cok = fx < nc;
+  d4 a0 = d4{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+  for (int rr = r0; rr < r1; rr += 8) {
+    const int ra = rr + fk, rb2 = rr + 4 + fk;
+    const double va = ra < r1 ? V[(long)ra * ldv + fx] : 0.0, ca = (ra < r1 && cok) ? C[(long)ra * ldc + fx] : 0.0;
+    const double vb = rb2 < r1 ? V[(long)rb2 * ldv + fx] : 0.0, cb = (rb2 < r1 && cok) ? C[(long)rb2 * ldc + fx] : 0.0;
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va, ca, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb, cb, a1, 0, 0, 0);
+  }
+  qrh_reduce_store(s_part, a0, a1, dst);
+}
+
+// ---- phase C: R2, the representation (W, K, S R), and the partials of X = V^T C for the next panel's columns ----
+template <int R>
+__global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
+  __shared__ double s_buf[QRH_LDS];
+  const int mat = blockIdx.y;
+  if ((int)blockIdx.x >= P.nrow) { qrh_side_apply(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  double* A = P.Wm + mat * P.strideW;
+  const int j0 = P.j0, M = P.M, N = P.N;
+  const long ld = P.ld;
+  const int c0 = j0 + NB, nc = N - c0 < NB ? N - c0 : NB;             // the next panel's columns (nc <= 0: none)
+  double* Xdst = P.Xp + mat * P.strideXp + (long)g * 256;
+  if (P.flag[mat]) {
+    if (g == 0) {
+      qr_panel_row_body<R>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
+      if (nc > 0) {
+        __threadfence();
+        __syncthreads();
+        qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)j0 * P.ldv + j0, P.ldv, A + (long)j0 * ld + c0, ld, M - j0, nc, Xdst);
+      }
+    } else if (nc > 0 && t < 256) Xdst[t] = 0.0;
+    return;
+  }
+  __shared__ double s_E[256], s_F[256], s_P[256], s_R1[256], s_Qt[256], s_R2[256], s_R2i[256], s_Z[256], s_Rm[256], s_K[256], s_S[16];
+  __shared__ int s_emax;
+  const int rb = j0 + (g * 8 + wave) * 64;
+  double a[4][4]; d4 cs[4];
+  qrh_load_rows(A, ld, j0, rb, M, a);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rb + q * 16 + fk + 4 * r;
+      cs[q][r] = (rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
+    }
+  }
+  if (t == 0) s_emax = 0;
+  __syncthreads();
+  const int i = (t & 255) / 16, j = t % 16;
+  if (t < 256) {
+    double x = 0.0;
+    for (int p = 0; p < P.ngp; p++) x += P.G2p[mat * P.strideG2 + (long)p * 256 + t];
+    x -= (i == j) ? 1.0 : 0.0;                                         // E = Q1^T Q1 - I
+    s_E[t] = x;
+    s_F[t] = (i < j) ? x : ((i == j) ? 0.5 * x : 0.0);
+    s_R1[t] = P.R1[(long)mat * 256 + t];
+    s_Qt[t] = A[(long)(j0 + i) * ld + j0 + j];
+    const float ax = fabsf((float)x);
+    atomicMax(&s_emax, (ax == ax) ? __float_as_int(ax) : 0x7f800000);
+  }
+  __syncthreads();
+  const bool series = __int_as_float(s_emax) <= (float)HR_SERIES_MAX;
+  if (series) {
+    // R2 = I + F with F = triu(E - F^T F) (diagonal halved), two fixed-point steps from F = triu(E): error O(|E|^3);
+    // R2^-1 = (I - F)(I + F^2) = I - F + F^2 - F^3: error O(|F|^4)
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += s_F[l * 16 + i] * s_F[l * 16 + j];
+      s_P[t] = pp;
+    }
+    __syncthreads();
+    if (t < 256) {
+      const double x = s_E[t] - s_P[t];
+      s_F[t] = (i < j) ? x : ((i == j) ? 0.5 * x : 0.0);
+    }
+    __syncthreads();
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += s_F[i * 16 + l] * s_F[l * 16 + j];
+      s_P[t] = pp + ((i == j) ? 1.0 : 0.0);                            // I + F^2
+      s_R2[t] = s_F[t] + ((i == j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += (((i == l) ? 1.0 : 0.0) - s_F[i * 16 + l]) * s_P[l * 16 + j];
+      s_R2i[t] = pp;
+    }
+  } else {
+    if (t < 256) s_E[t] += (i == j) ? 1.0 : 0.0;
+    __syncthreads();
+    if (wave == 0) (void)qrh_chol16(s_E, s_R2, s_R2i, 0.0);
+  }
+  __syncthreads();
+  if (t < 256) {
+    double z = 0.0, rr = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; l++) {
+      z += s_Qt[i * 16 + l] * s_R2i[l * 16 + j];                       // top block of Q = Q1 R2^-1
+      rr += s_R2[i * 16 + l] * s_R1[l * 16 + j];                       // R = R2 R1
+    }
+    s_Z[t] = z; s_Rm[t] = rr;
+  }
+  __syncthreads();
+  if (wave == 0) qrh_gj16(s_Z, s_K, s_S);
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
+  d4 y[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    y[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) y[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], bw[kk], y[q], 0, 0, 0);
+  }
+  __syncthreads();                                                     // s_K, s_S
+  double* V = P.Vall + mat * P.strideV + j0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const bool top = (g == 0 && wave == 0 && q == 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int ii = fk + 4 * r, rc = rb + q * 16 + ii;
+      double wv = 0.0;
+      if (top) {                                                       // W = Q - [S; 0]; R = S R2 R1 in place
+        if (ii == fx) y[q][r] -= s_S[ii];
+        wv = (ii <= fx) ? s_S[ii] * s_Rm[ii * 16 + fx] : 0.0;
+      }
+      if (rc < M) { V[(long)rc * P.ldv + fx] = y[q][r]; A[(long)rc * ld + j0 + fx] = wv; }
+    }
+  }
+  if (g == 0) {
+    if (t < 256) P.Tall[mat * P.strideT + (long)(j0 / NB) * NB * NB + t] = s_K[t];
+    if (t < 16) P.taus[mat * P.strideTau + j0 + t] = 1.0;             // "a reflector was needed" (qr_flips)
+  }
+  if (nc > 0) {
+    d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][0], cs[q][0], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][1], cs[q][1], x1, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][2], cs[q][2], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][3], cs[q][3], x1, 0, 0, 0);
+    }
+    qrh_reduce_store(s_buf, x0, x1, Xdst);
+  }
 }
 
 // ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
@@ -855,10 +1386,10 @@ __global__ __launch_bounds__(256) void qr_tw(const double* __restrict__ Tall, lo
     double s = 0.0;
     if (trans) {
 #pragma unroll
-      for (int j = 0; j < NB; j++) if (j <= i) s += s_T[j][i] * w[j];
+      for (int j = 0; j < NB; j++) s += s_T[j][i] * w[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < NB; j++) if (j >= i) s += s_T[i][j] * w[j];
+      for (int j = 0; j < NB; j++) s += s_T[i][j] * w[j];
     }
     W2[(long)i * ldw + col] = s;
   }
@@ -1087,8 +1618,13 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   const bool lookahead = !la_off && M <= 2048 && M >= 64;
   const bool use_qt = lookahead && !wy_off && !qt_off && batch <= 4 && L >= 256;   // Q^T accumulated in the shadow of the panels
   const long sQT = use_qt ? (long)M * M : 0;
-  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT);
-  size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + 64;
+  static const bool hr_off = [] { const char* e = getenv("ND4HIP_QR_NO_HR"); return e && *e && *e != '0'; }();
+  const bool use_hr = lookahead && !hr_off;                  // multi-workgroup panels (CholeskyQR2 + Householder reconstruction)
+  const int hr_parts = (M + NB + 511) / 512 + 1;
+  const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 256 : 0, sR1 = use_hr ? 256 : 0;
+  const long sXs = use_hr ? (long)((N + NB - 1) / NB + (use_qt ? (M + NB - 1) / NB : 0)) * ((M + 511) / 512) * 256 : 0;   // [column block][row chunk][256]
+  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT + sGp + sG2 + sR1 + sXs);
+  size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + (size_t)batch * sizeof(int) + 64;
   void* p = nullptr;
   Nd4WsScope scope(h);
   ND4_TRY(nd4_ws_alloc(h, bytes, &p));
@@ -1101,12 +1637,17 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   ws.W2 = d; d += (size_t)batch * ws.sW2;
   ws.work = tall ? d : nullptr; d += (size_t)batch * sWork;
   double* QT = use_qt ? d : nullptr; d += (size_t)batch * sQT;
+  double* hrGp = d; d += (size_t)batch * sGp;
+  double* hrG2 = d; d += (size_t)batch * sG2;
+  double* hrR1 = d; d += (size_t)batch * sR1;
+  double* hrXs = d; d += (size_t)batch * sXs;
   ws.flips = reinterpret_cast<int*>(d);
 
   // working matrix: R's buffer when it has A's shape (M <= N), a workspace copy when tall
   double* W = tall ? ws.work : R;
   const long ld = N, sW = (long)M * N;
   unsigned long long* exps = reinterpret_cast<unsigned long long*>(ws.flips + (((size_t)batch * L + 1) & ~size_t(1)));   // max|a| bits per matrix
+  int* hrFlag = reinterpret_cast<int*>(exps + batch);
   ND4_HIP(hipMemsetAsync(exps, 0, sizeof(unsigned long long) * batch, h->stream));
   {
     long nblk = (sW + 256 * 16 - 1) / (256 * 16); if (nblk > 2048) nblk = 2048;
@@ -1123,7 +1664,43 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     int pj0 = -1;                                            // first row/column of the previous panel
     const int nq = QT ? (M + NB - 1) / NB : 0;
     if (QT) ND4_TRY(nd4_set_identity(h, M, M, QT, M, batch, sQT));
-    for (int pnl = 0; pnl < npanels; pnl++) {
+    int pnl = 0;
+    if (use_hr) {
+      // multi-workgroup panels while they are full and tall enough: three launches per panel (Gram / Cholesky / reconstruction), the
+      // previous reflector's column blocks spread over them (its first block of trailing columns is what phase C reads: it goes first)
+      QrhP P;
+      P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
+      P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
+      P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
+      for (; pnl < npanels; pnl++) {
+        const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
+        if (nb < NB || m < HR_MIN_ROWS) break;
+        const int wide0 = pj0 + 2 * NB;
+        P.j0 = j0; P.pj0 = pj0; P.wide0 = wide0;
+        P.nwide = (pj0 >= 0 && wide0 < N) ? (N - wide0 + NB - 1) / NB : 0;
+        P.nq = pj0 >= 0 ? nq : 0;
+        P.nrc = pj0 >= 0 ? (M - pj0 + 511) / 512 : 1;
+        const int nA = (m + NB + 511) / 512, nB = (m + 511) / 512;
+        // A: partial X of every side block; B: the update of the trailing columns (phase C reads the first of them); C: Q^T
+        P.nrow = nA; P.ngp = 0; P.cb0 = 0;
+        hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + (P.nwide + P.nq) * P.nrc), (unsigned)batch), dim3(512), 0, h->stream, P);
+        P.nrow = nB; P.ngp = nA; P.cb0 = 0;
+        hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + P.nwide * P.nrc), (unsigned)batch), dim3(512), 0, h->stream, P);
+        P.ngp = nB; P.cb0 = P.nwide;
+        const dim3 gc((unsigned)(nB + P.nq * P.nrc), (unsigned)batch);
+        if (m <= 512)       hipLaunchKernelGGL(qrh_reconstruct<1>, gc, dim3(512), 0, h->stream, P);
+        else if (m <= 1024) hipLaunchKernelGGL(qrh_reconstruct<2>, gc, dim3(512), 0, h->stream, P);
+        else                hipLaunchKernelGGL(qrh_reconstruct<4>, gc, dim3(512), 0, h->stream, P);
+        pj0 = j0; P.nxp = nB;
+      }
+      if (pj0 >= 0 && pj0 + NB < N) {                          // the last such reflector on the 16 columns behind its panel
+        const int m = M - pj0;
+        hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                           W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, pj0, pj0 + NB, ws.Wp, ws.sWb, P.nxp);
+      }
+      ND4_HIP(hipGetLastError());
+    }
+    for (; pnl < npanels; pnl++) {
       const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
       // reflector p-1 has reached the 16 columns behind its own panel (the narrow launch: [pj0 + NB, pj0 + 2 NB), which contain this
       // panel); the columns from there on still lack it
@@ -1136,7 +1713,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
       if (wc0 < N) {                                           // the next panel's columns (or the first block right of the last panel)
         const dim3 gn((unsigned)((m + 255) / 256), (unsigned)batch);
         hipLaunchKernelGGL(qr_narrow_x, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, j0, wc0, ws.Wp, ws.sWb);
-        hipLaunchKernelGGL(qr_narrow_apply, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0, ws.Wp, ws.sWb);
+        hipLaunchKernelGGL(qr_narrow_apply, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0, ws.Wp, ws.sWb, 0);
       }
       pj0 = j0;
     }
