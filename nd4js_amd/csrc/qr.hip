@@ -624,6 +624,9 @@ constexpr double HR_PIVOT_THR = 1e-5;
 constexpr double HR_SERIES_MAX = 1e-5;
 constexpr int HR_MIN_ROWS = 64;
 
+enum { SEG_NX = 0, SEG_NA };
+struct QrhSeg { int kind, first, count; };
+
 struct QrhP {
   double* Wm; int M, N; long ld, strideW;
   double* Vall; long ldv, strideV;
@@ -640,8 +643,9 @@ struct QrhP {
   int nxp;                          // partials of X to sum in phase A
   int nrow;                         // row workgroups of this launch
   int ngp;                          // Gram partials to sum (phase B: phase A's row workgroups; phase C: phase B's)
-  int wide0, nwide, nq, nrc;        // side work: nwide column blocks of W from wide0 on, then nq column blocks of Q^T, nrc row chunks each
-  int cb0;                          // first column block of this launch's side work (workgroup -> block cb0 + i / nrc, chunk i % nrc)
+  int wide0, nnw, nrc;              // side work (reflector pj0): nnw column blocks of W from wide0 on (then blocks of Q^T), nrc row chunks each
+  int nseg; QrhSeg seg[2];          // the side work of this launch: workgroups nrow.. walk these segments
+  long long* stamps; int stamp_slot; // debug (ND4HIP_QR_STAMPS): 100 MHz wall-clock stamps of workgroup 0, 8 per launch
 };
 
 template <int K, int I>
@@ -729,8 +733,22 @@ __device__ __forceinline__ void qrh_gj16(const double* __restrict__ s_Z, double*
   }
 }
 
-constexpr int QRH_LDS = 8 * 256 + 256 + NB * (NB + 1) + 16;      // doubles: what qr_colblock_update<512> needs; the phases carve the same buffer
+constexpr int QRH_LDS = 8 * 256 + 256 + NB * (NB + 1) + 16;      // doubles: what the row phases and the side work need ...
+constexpr int QRH_SMEM = QRH_LDS + 11 * 256 + 32;                // ... and the whole per-workgroup buffer: phase C carves its 16 x 16 matrices behind QRH_LDS
 
+// sum of n partials (256 doubles apart) of one entry, fixed order; the loads are issued together (a rolled loop of dependent
+// global loads costs a full memory round trip per partial: 1-1.5 us each behind a kernel boundary)
+__device__ __forceinline__ double qrh_sum_parts(const double* __restrict__ src, int n) {
+  double x = 0.0;
+  for (int p0 = 0; p0 < n; p0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) v[p] = (p0 + p < n) ? src[(long)(p0 + p) * 256] : 0.0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) x += v[p];
+  }
+  return x;
+}
 // fixed-order sum of the eight waves' 16 x 16 accumulators -> dst[256] (global)
 __device__ __forceinline__ void qrh_reduce_store(double* __restrict__ s_part, const d4& a0, const d4& a1, double* __restrict__ dst) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
@@ -772,9 +790,7 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
   double* s_X = s_w;
   double* s_Tm = s_w + 256;
   if (t < 256) {
-    double x = 0.0;
-    for (int p = 0; p < nx; p++) x += Xsrc[(long)p * 256 + t];
-    s_X[t] = x;
+    s_X[t] = qrh_sum_parts(Xsrc + t, nx);
     s_Tm[t] = Tg[t];
   }
   __syncthreads();
@@ -802,60 +818,85 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
   }
 }
 
-// ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks, in two phases ----
+// ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks (trailing columns of W, then
+// Q^T), in two phases split over 512-row chunks like the panel itself: partial X = V^T C (SEG_NX, launch A), C -= V (T^T X)
+// (SEG_NA: the blocks of W in launch B, whose first one phase C reads; those of Q^T in launch C) ----
 struct QrhSide { double* C; long ldc; int c0, nc, cb, rc; };
-__device__ __forceinline__ QrhSide qrh_side_of(const QrhP& P, int mat, int i) {
+__device__ __forceinline__ QrhSide qrh_near_of(const QrhP& P, int mat, int e) {
   QrhSide s;
-  s.cb = P.cb0 + i / P.nrc; s.rc = i % P.nrc;
-  if (s.cb < P.nwide) { s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB; s.nc = P.N - s.c0 < NB ? P.N - s.c0 : NB; }
-  else                { s.C = P.QT + mat * P.strideQT; s.ldc = P.M; s.c0 = (s.cb - P.nwide) * NB; s.nc = P.M - s.c0 < NB ? P.M - s.c0 : NB; }
+  s.cb = e / P.nrc; s.rc = e % P.nrc;
+  if (s.cb < P.nnw) { s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB; s.nc = P.N - s.c0 < NB ? P.N - s.c0 : NB; }
+  else              { s.C = P.QT + mat * P.strideQT; s.ldc = P.M; s.c0 = (s.cb - P.nnw) * NB; s.nc = P.M - s.c0 < NB ? P.M - s.c0 : NB; }
   return s;
 }
-// partial X = V^T C over one 512-row chunk of one column block
-__device__ __forceinline__ void qrh_side_x(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
-  const QrhSide s = qrh_side_of(P, mat, i);
+// partial X = V^T C over one 512-row chunk of one column block (the reflector at vj0)
+__device__ __forceinline__ void qrh_side_x(const QrhP& P, int mat, const QrhSide& s, int vj0, double* __restrict__ dst, double* __restrict__ s_buf) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
-  const int rb = P.pj0 + s.rc * 512 + wave * 64;
-  const double* V = P.Vall + mat * P.strideV + P.pj0;
+  const int rb = vj0 + s.rc * 512 + wave * 64;
+  const double* V = P.Vall + mat * P.strideV + vj0;
   const bool cok = fx < s.nc;
-  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
-  double v[16], c[16];
+  double c[16], v[16];
 #pragma unroll
   for (int u = 0; u < 16; u++) {                                       // 16 slabs of 4 rows: both operands in the same (row fk, column fx) layout
     const int r = rb + 4 * u + fk;
-    v[u] = r < P.M ? V[(long)r * P.ldv + fx] : 0.0;
     c[u] = (r < P.M && cok) ? s.C[(long)r * s.ldc + s.c0 + fx] : 0.0;
+    v[u] = r < P.M ? V[(long)r * P.ldv + fx] : 0.0;
   }
+  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
 #pragma unroll
   for (int u = 0; u < 16; u += 2) {
     x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c[u], x0, 0, 0, 0);
     x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c[u + 1], x1, 0, 0, 0);
   }
-  qrh_reduce_store(s_buf, x0, x1, P.Xs + mat * P.strideXs + ((long)s.cb * P.nrc + s.rc) * 256);
+  qrh_reduce_store(s_buf, x0, x1, dst);
 }
-// C -= V (T^T X) on one 512-row chunk of one column block
-__device__ __forceinline__ void qrh_side_apply(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
-  const QrhSide s = qrh_side_of(P, mat, i);
+// C -= V (T^T X) on one 512-row chunk of one near column block
+__device__ __forceinline__ void qrh_near_apply(const QrhP& P, int mat, int e, double* __restrict__ s_buf) {
+  const QrhSide s = qrh_near_of(P, mat, e);
   const int wave = threadIdx.x >> 6;
   d4 c[4];
   qrh_apply_rows(s_buf, P.Xs + mat * P.strideXs + (long)s.cb * P.nrc * 256, P.nrc, P.Tall + mat * P.strideT + (long)(P.pj0 / NB) * NB * NB,
                  P.Vall + mat * P.strideV + P.pj0, P.ldv, s.C + s.c0, s.ldc, s.nc, P.pj0 + s.rc * 512 + wave * 64, P.M, c);
 }
+// workgroup i of a launch's side work
+__device__ __forceinline__ void qrh_side(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
+  int kind = -1, e = 0;
+  for (int sg = 0; sg < P.nseg; sg++) {
+    if (i < P.seg[sg].count) { kind = P.seg[sg].kind; e = P.seg[sg].first + i; break; }
+    i -= P.seg[sg].count;
+  }
+  if (kind == SEG_NX) {
+    const QrhSide s = qrh_near_of(P, mat, e);
+    qrh_side_x(P, mat, s, P.pj0, P.Xs + mat * P.strideXs + ((long)s.cb * P.nrc + s.rc) * 256, s_buf);
+  } else if (kind == SEG_NA) {
+    qrh_near_apply(P, mat, e, s_buf);
+  }
+}
+// side work on its own (the flush after the last such panel)
+__global__ __launch_bounds__(512) void qrh_side_only(const QrhP P) {
+  __shared__ double s_buf[QRH_SMEM];
+  qrh_side(P, blockIdx.y, blockIdx.x, s_buf);
+}
 
+__device__ __forceinline__ void qrh_stamp(const QrhP& P, int k) {
+  if (P.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.stamps[P.stamp_slot * 8 + k] = wall_clock64();
+}
 // ---- phase A: the previous reflector on the panel's own columns (rows from j0 - 16), then the partial Gram matrices ----
 __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
-  __shared__ double s_buf[QRH_LDS];
+  __shared__ double s_buf[QRH_SMEM];
   const int mat = blockIdx.y;
-  if ((int)blockIdx.x >= P.nrow) { qrh_side_x(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  if ((int)blockIdx.x >= P.nrow) { qrh_side(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
   double* A = P.Wm + mat * P.strideW;
   const int j0 = P.j0, ub = j0 - NB, M = P.M;
   const int rb = ub + (g * 8 + wave) * 64;
   d4 c[4];
+  qrh_stamp(P, 0);
   if (P.pj0 >= 0) {
     qrh_apply_rows(s_buf, P.Xp + mat * P.strideXp, P.nxp, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
                    P.Vall + mat * P.strideV + ub, P.ldv, A + j0, P.ld, NB, rb, M, c);
     __syncthreads();                                                  // s_buf is reused below
+    qrh_stamp(P, 1);
   } else {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -886,6 +927,7 @@ __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
     for (int r = 0; r < 4; r++) P.Gp[mat * P.strideGp + (fk + 4 * r) * 16 + fx] = gt[r];
   }
   qrh_reduce_store(s_buf, g0, g1, P.Gp + mat * P.strideGp + (long)(1 + g) * 256);
+  qrh_stamp(P, 4);
 }
 
 // the wave's 64 rows of the panel's 16 columns as MFMA A operands (k-step kk <-> column 4 fk + kk: 32 contiguous bytes per lane)
@@ -907,11 +949,11 @@ __device__ __forceinline__ void qrh_load_rows(const double* __restrict__ A, long
 
 // ---- phase B: R1 = chol(G), Q1 = C R1^-1 in place, partial Gram matrices of Q1; decides the fall-back ----
 __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
-  __shared__ double s_buf[QRH_LDS];
+  __shared__ double s_buf[QRH_SMEM];
   __shared__ double s_G[256], s_R[256], s_Ri[256], s_db[16];
   __shared__ int s_flag;
   const int mat = blockIdx.y;
-  if ((int)blockIdx.x >= P.nrow) { qrh_side_apply(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  if ((int)blockIdx.x >= P.nrow) { qrh_side(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
   double* A = P.Wm + mat * P.strideW;
   const int j0 = P.j0, M = P.M;
@@ -919,13 +961,14 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
   const int rb = j0 + (g * 8 + wave) * 64;
   double a[4][4];
   qrh_load_rows(A, ld, j0, rb, M, a);
+  qrh_stamp(P, 0);
   if (t < 256) {
-    double gb = 0.0;
-    for (int p = 0; p < P.ngp; p++) gb += P.Gp[mat * P.strideGp + (long)(1 + p) * 256 + t];
+    const double gb = qrh_sum_parts(P.Gp + mat * P.strideGp + 256 + t, P.ngp);
     s_G[t] = gb + P.Gp[mat * P.strideGp + t];
     if (t % 17 == 0) s_db[t / 17] = gb;                               // column sums of squares below the top block
   }
   __syncthreads();
+  qrh_stamp(P, 1);
   if (wave == 0) {
     bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
 #pragma unroll
@@ -934,6 +977,7 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
   }
   __syncthreads();
   const int flag = s_flag;
+  qrh_stamp(P, 2);
   if (g == 0) {
     if (t == 0) P.flag[mat] = flag;
     if (t < 256) P.R1[(long)mat * 256 + t] = s_R[t];
@@ -963,6 +1007,7 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
     g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][3], acc[q][3], g1, 0, 0, 0);
   }
   qrh_reduce_store(s_buf, g0, g1, P.G2p + mat * P.strideG2 + (long)g * 256);
+  qrh_stamp(P, 4);
 }
 
 // X = V^T C over all m rows by the eight waves of one workgroup -> dst[256] (the fall-back panel's share of phase C)
@@ -986,9 +1031,9 @@ __device__ __forceinline__ void qrh_x_full(double* __restrict__ s_part, const do
 // ---- phase C: R2, the representation (W, K, S R), and the partials of X = V^T C for the next panel's columns ----
 template <int R>
 __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
-  __shared__ double s_buf[QRH_LDS];
+  __shared__ double s_buf[QRH_SMEM];
   const int mat = blockIdx.y;
-  if ((int)blockIdx.x >= P.nrow) { qrh_side_apply(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  if ((int)blockIdx.x >= P.nrow) { qrh_side(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
   double* A = P.Wm + mat * P.strideW;
   const int j0 = P.j0, M = P.M, N = P.N;
@@ -998,19 +1043,19 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   if (P.flag[mat]) {
     if (g == 0) {
       qr_panel_row_body<R>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
-      if (nc > 0) {
-        __threadfence();
-        __syncthreads();
-        qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)j0 * P.ldv + j0, P.ldv, A + (long)j0 * ld + c0, ld, M - j0, nc, Xdst);
-      }
+      __threadfence();
+      __syncthreads();
+      if (nc > 0) qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)j0 * P.ldv + j0, P.ldv, A + (long)j0 * ld + c0, ld, M - j0, nc, Xdst);
     } else if (nc > 0 && t < 256) Xdst[t] = 0.0;
     return;
   }
-  __shared__ double s_E[256], s_F[256], s_P[256], s_R1[256], s_Qt[256], s_R2[256], s_R2i[256], s_Z[256], s_Rm[256], s_K[256], s_S[16];
+  double* s_E = s_buf + QRH_LDS; double* s_F = s_E + 256; double* s_P = s_F + 256; double* s_R1 = s_P + 256; double* s_Qt = s_R1 + 256;
+  double* s_R2 = s_Qt + 256; double* s_R2i = s_R2 + 256; double* s_Z = s_R2i + 256; double* s_Rm = s_Z + 256; double* s_K = s_Rm + 256; double* s_S = s_K + 256;
   __shared__ int s_emax;
   const int rb = j0 + (g * 8 + wave) * 64;
   double a[4][4]; d4 cs[4];
   qrh_load_rows(A, ld, j0, rb, M, a);
+  qrh_stamp(P, 0);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -1019,22 +1064,27 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
       cs[q][r] = (rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
     }
   }
+  const int i = (t & 255) / 16, j = t % 16;
+  double x = 0.0, r1v = 0.0, qtv = 0.0;
+  if (t < 256) {
+    x = qrh_sum_parts(P.G2p + mat * P.strideG2 + t, P.ngp);
+    r1v = P.R1[(long)mat * 256 + t];
+    qtv = A[(long)(j0 + i) * ld + j0 + j];
+  }
   if (t == 0) s_emax = 0;
   __syncthreads();
-  const int i = (t & 255) / 16, j = t % 16;
   if (t < 256) {
-    double x = 0.0;
-    for (int p = 0; p < P.ngp; p++) x += P.G2p[mat * P.strideG2 + (long)p * 256 + t];
     x -= (i == j) ? 1.0 : 0.0;                                         // E = Q1^T Q1 - I
     s_E[t] = x;
     s_F[t] = (i < j) ? x : ((i == j) ? 0.5 * x : 0.0);
-    s_R1[t] = P.R1[(long)mat * 256 + t];
-    s_Qt[t] = A[(long)(j0 + i) * ld + j0 + j];
+    s_R1[t] = r1v;
+    s_Qt[t] = qtv;
     const float ax = fabsf((float)x);
     atomicMax(&s_emax, (ax == ax) ? __float_as_int(ax) : 0x7f800000);
   }
   __syncthreads();
   const bool series = __int_as_float(s_emax) <= (float)HR_SERIES_MAX;
+  qrh_stamp(P, 1);
   if (series) {
     // R2 = I + F with F = triu(E - F^T F) (diagonal halved), two fixed-point steps from F = triu(E): error O(|E|^3);
     // R2^-1 = (I - F)(I + F^2) = I - F + F^2 - F^3: error O(|F|^4)
@@ -1080,6 +1130,7 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
     s_Z[t] = z; s_Rm[t] = rr;
   }
   __syncthreads();
+  qrh_stamp(P, 3);
   if (wave == 0) qrh_gj16(s_Z, s_K, s_S);
   double bw[4];
 #pragma unroll
@@ -1092,6 +1143,7 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
     for (int kk = 0; kk < 4; kk++) y[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], bw[kk], y[q], 0, 0, 0);
   }
   __syncthreads();                                                     // s_K, s_S
+  qrh_stamp(P, 4);
   double* V = P.Vall + mat * P.strideV + j0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -1122,6 +1174,8 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
     }
     qrh_reduce_store(s_buf, x0, x1, Xdst);
   }
+  qrh_stamp(P, 5);
+  qrh_stamp(P, 6);
 }
 
 // ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
@@ -1619,10 +1673,11 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   const bool use_qt = lookahead && !wy_off && !qt_off && batch <= 4 && L >= 256;   // Q^T accumulated in the shadow of the panels
   const long sQT = use_qt ? (long)M * M : 0;
   static const bool hr_off = [] { const char* e = getenv("ND4HIP_QR_NO_HR"); return e && *e && *e != '0'; }();
-  const bool use_hr = lookahead && !hr_off;                  // multi-workgroup panels (CholeskyQR2 + Householder reconstruction)
+  const bool use_hr = lookahead && !hr_off && batch <= 8;    // multi-workgroup panels (CholeskyQR2 + compact orthogonal completion)
   const int hr_parts = (M + NB + 511) / 512 + 1;
   const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 256 : 0, sR1 = use_hr ? 256 : 0;
-  const long sXs = use_hr ? (long)((N + NB - 1) / NB + (use_qt ? (M + NB - 1) / NB : 0)) * ((M + 511) / 512) * 256 : 0;   // [column block][row chunk][256]
+  const long hr_rcs = (M + 511) / 512;
+  const long sXs = use_hr ? ((N + NB - 1) / NB + (use_qt ? (M + NB - 1) / NB : 0)) * hr_rcs * 256 : 0;   // side work: [column block][row chunk][256]
   size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT + sGp + sG2 + sR1 + sXs);
   size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + (size_t)batch * sizeof(int) + 64;
   void* p = nullptr;
@@ -1666,37 +1721,71 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     if (QT) ND4_TRY(nd4_set_identity(h, M, M, QT, M, batch, sQT));
     int pnl = 0;
     if (use_hr) {
-      // multi-workgroup panels while they are full and tall enough: three launches per panel (Gram / Cholesky / reconstruction), the
-      // previous reflector's column blocks spread over them (its first block of trailing columns is what phase C reads: it goes first)
+      // multi-workgroup panels while they are full and tall enough: three launches per panel (Gram / Cholesky / representation). The
+      // previous reflector's side work rides along: partial X of every column block (trailing columns of W, then Q^T) in launch A,
+      // the update of the blocks of W in launch B (phase C reads the first of them), of Q^T in launch C.
       QrhP P;
       P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
       P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
       P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
+      P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0;
+      static const int hr_min_rows = [] { const char* e = getenv("ND4HIP_QR_HR_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= HR_MIN_ROWS ? v : HR_MIN_ROWS; }();
+      static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
+      P.stamps = nullptr; P.stamp_slot = 0;
+      if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
+      auto add_seg = [&](int kind, int first, int count) { if (count > 0) { P.seg[P.nseg].kind = kind; P.seg[P.nseg].first = first; P.seg[P.nseg].count = count; P.nseg++; } };
+      auto seg_total = [&]() { int n = 0; for (int i = 0; i < P.nseg; i++) n += P.seg[i].count; return n; };
+      auto side_launch = [&]() { if (P.nseg > 0) hipLaunchKernelGGL(qrh_side_only, dim3((unsigned)seg_total(), (unsigned)batch), dim3(512), 0, h->stream, P); P.nseg = 0; };
+      auto side_of = [&](int pj, int& nw_e, int& all_e) {      // the side work of the reflector at pj: workgroups for W, for W and Q^T
+        nw_e = 0; all_e = 0;
+        if (pj < 0) return;
+        const int wide0 = pj + 2 * NB;
+        P.wide0 = wide0; P.nrc = (M - pj + 511) / 512;
+        P.nnw = wide0 < N ? (N - wide0 + NB - 1) / NB : 0;
+        nw_e = P.nnw * P.nrc; all_e = nw_e + nq * P.nrc;
+      };
       for (; pnl < npanels; pnl++) {
         const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
-        if (nb < NB || m < HR_MIN_ROWS) break;
-        const int wide0 = pj0 + 2 * NB;
-        P.j0 = j0; P.pj0 = pj0; P.wide0 = wide0;
-        P.nwide = (pj0 >= 0 && wide0 < N) ? (N - wide0 + NB - 1) / NB : 0;
-        P.nq = pj0 >= 0 ? nq : 0;
-        P.nrc = pj0 >= 0 ? (M - pj0 + 511) / 512 : 1;
+        if (nb < NB || m < hr_min_rows) break;
+        int side_w = 0, side_all = 0;
+        side_of(pj0, side_w, side_all);
+        P.j0 = j0; P.pj0 = pj0;
         const int nA = (m + NB + 511) / 512, nB = (m + 511) / 512;
-        // A: partial X of every side block; B: the update of the trailing columns (phase C reads the first of them); C: Q^T
-        P.nrow = nA; P.ngp = 0; P.cb0 = 0;
-        hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + (P.nwide + P.nq) * P.nrc), (unsigned)batch), dim3(512), 0, h->stream, P);
-        P.nrow = nB; P.ngp = nA; P.cb0 = 0;
-        hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + P.nwide * P.nrc), (unsigned)batch), dim3(512), 0, h->stream, P);
-        P.ngp = nB; P.cb0 = P.nwide;
-        const dim3 gc((unsigned)(nB + P.nq * P.nrc), (unsigned)batch);
+        P.nrow = nA; P.ngp = 0; P.nseg = 0; add_seg(SEG_NX, 0, side_all);
+        hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+        P.nrow = nB; P.ngp = nA; P.nseg = 0; add_seg(SEG_NA, 0, side_w);
+        hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+        P.ngp = nB; P.nseg = 0; add_seg(SEG_NA, side_w, side_all - side_w);
+        const dim3 gc((unsigned)(nB + seg_total()), (unsigned)batch);
         if (m <= 512)       hipLaunchKernelGGL(qrh_reconstruct<1>, gc, dim3(512), 0, h->stream, P);
         else if (m <= 1024) hipLaunchKernelGGL(qrh_reconstruct<2>, gc, dim3(512), 0, h->stream, P);
         else                hipLaunchKernelGGL(qrh_reconstruct<4>, gc, dim3(512), 0, h->stream, P);
-        pj0 = j0; P.nxp = nB;
+        pj0 = j0; P.nxp = nB; P.nseg = 0; P.stamp_slot++;
       }
-      if (pj0 >= 0 && pj0 + NB < N) {                          // the last such reflector on the 16 columns behind its panel
-        const int m = M - pj0;
-        hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                           W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, pj0, pj0 + NB, ws.Wp, ws.sWb, P.nxp);
+      if (pj0 >= 0) {
+        // the last such reflector: the 16 columns behind its panel, then its side work on its own
+        if (pj0 + NB < N) {
+          const int m = M - pj0;
+          hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                             W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, pj0, pj0 + NB, ws.Wp, ws.sWb, P.nxp);
+        }
+        int side_w = 0, side_all = 0;
+        side_of(pj0, side_w, side_all);
+        P.pj0 = pj0;
+        P.nseg = 0; add_seg(SEG_NX, 0, side_all); side_launch();
+        add_seg(SEG_NA, 0, side_all); side_launch();
+        pj0 = -1;                                              // nothing pending: the remaining panels start afresh
+      }
+      if (P.stamps) {                                          // debug: per launch, the stamps of workgroup 0 relative to the first one, in us
+        std::vector<long long> st((size_t)8 * P.stamp_slot);
+        ND4_HIP(hipStreamSynchronize(h->stream));
+        ND4_HIP(hipMemcpy(st.data(), P.stamps, sizeof(long long) * st.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(P.stamps);
+        for (int i = 0; i < P.stamp_slot; i++) {
+          fprintf(stderr, "qrh stamp launch %d (%c panel %d):", i, "ABC"[i % 3], i / 3);
+          for (int k = 0; k < 8; k++) fprintf(stderr, " %.2f", st[i * 8 + k] ? (st[i * 8 + k] - st[0]) * 0.01 : 0.0);
+          fprintf(stderr, "\n");
+        }
       }
       ND4_HIP(hipGetLastError());
     }
@@ -1717,14 +1806,14 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
       }
       pj0 = j0;
     }
-    {   // wide input: the last reflector on the columns right of the block the narrow launch has done
+    if (pj0 >= 0) {   // the last panel was a thread-per-row one; wide input: its reflector on the columns right of the block the narrow launch has done
       const int j0 = (npanels - 1) * NB, nb = L - j0 < NB ? L - j0 : NB, wc0 = j0 + nb + NB;
       if (wc0 < N)
         hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)((N - wc0 + NB - 1) / NB), (unsigned)batch), dim3(512), 0, h->stream,
                            W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0);
+      if (QT) hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)nq, (unsigned)batch), dim3(512), 0, h->stream,
+                                 QT, M, M, (long)M, sQT, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, (npanels - 1) * NB, 0);
     }
-    if (QT) hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)nq, (unsigned)batch), dim3(512), 0, h->stream,
-                               QT, M, M, (long)M, sQT, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, (npanels - 1) * NB, 0);
     ND4_HIP(hipGetLastError());
   } else
   for (int pnl = 0; pnl < npanels; pnl++) {
