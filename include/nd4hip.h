@@ -220,6 +220,26 @@ int nd4hip_dgeqr2_panel_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, 
  * were found during the last sweep (<= N*eps at convergence). Any pointer may be NULL. */
 int nd4hip_dgesvdj_last_info(nd4hip_handle* h, int* sweeps, unsigned long long* rotations, double* offnorm);
 
+/* ---- per-call profile (SURVEY.md 8b `nd4hip_profile_last`; the reference times calls with performance.now(),
+ * benchmarks/bench_la_decomps.html:218-224) ---------------------------------------------------------------------
+ * nd4hip_profile_enable(h, 1): from now on every device-side entry point (the *_dev forms; the host-pointer forms run them per
+ * chunk and per device) brackets its kernels with two HIP events on the handle's stream and records the ALGORITHMIC work of the
+ * call (SURVEY.md 8d conventions: matmul 2 I K J, LU 2/3 N^3, QR with explicit Q 4 (M N^2 - N^3 / 3) for M >= N, SVD nominal
+ * 4 M^2 N + 8 M N^2 + 9 N^3, ...; bytes = every operand read once and every result written once). Off by default (two event
+ * records per call). nd4hip_profile_last fills one record per device of the handle (capacity entries at most; a multi-device
+ * handle's devices each report the last block they ran), waits for those kernels to finish, and returns the number of devices.
+ * For a host-pointer call that was cut into chunks a record describes the LAST chunk of that device. */
+typedef struct nd4hip_prof {
+  double kernel_ms;   /* HIP-event time between the first and the last kernel of the call on this device */
+  double flops;       /* algorithmic flops of the call (0 for pure data movement) */
+  double bytes;       /* algorithmic HBM bytes of the call */
+  int    device;      /* HIP device id */
+  int    valid;       /* 0: nothing recorded on this device yet */
+  char   op[32];      /* entry point without the nd4hip_ prefix, e.g. "dgetrf_batched" */
+} nd4hip_prof;
+int nd4hip_profile_enable(nd4hip_handle* h, int on);
+int nd4hip_profile_last(nd4hip_handle* h, nd4hip_prof* out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

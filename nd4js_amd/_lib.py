@@ -72,9 +72,17 @@ SIGNATURES = {
     "nd4hip_dgesvdj_batched": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp, c_dp,
                                        ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "nd4hip_dgeqr2_panel_batched_dev": (c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, c_dp, c_dp, c_dp]),
+    "nd4hip_profile_enable": (c_int, [ctypes.c_void_p, c_int]),
+    "nd4hip_profile_last": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int]),
     "nd4hip_dgesvdj_last_info": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_ulonglong),
                                          ctypes.POINTER(ctypes.c_double)]),
 }
+
+
+class Prof(ctypes.Structure):
+    """nd4hip_prof of include/nd4hip.h"""
+    _fields_ = [("kernel_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("device", c_int), ("valid", c_int), ("op", ctypes.c_char * 32)]
 
 
 class Nd4HipError(RuntimeError):
@@ -145,6 +153,18 @@ class Handle:
         ms = ctypes.c_float()
         check(self.lib.nd4hip_timer_stop(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def profile_enable(self, on=True):
+        check(self.lib.nd4hip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_last(self):
+        """one record per device of the handle: kernel ms, algorithmic flops / bytes of the last call (nd4hip_profile_last)"""
+        recs = (Prof * 64)()
+        n = self.lib.nd4hip_profile_last(self._h, ctypes.cast(recs, ctypes.c_void_p), 64)
+        if n < 0:
+            check(n)
+        return [{"device": r.device, "valid": bool(r.valid), "op": r.op.decode(), "kernel_ms": r.kernel_ms, "flops": r.flops,
+                 "bytes": r.bytes} for r in recs[:n]]
 
     def svd_last_info(self):
         """sweeps, rotations applied and off-norm of the last svd_decomp on this handle (executed-work audit)"""

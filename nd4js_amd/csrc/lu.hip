@@ -200,15 +200,21 @@ __device__ __forceinline__ void lu_panel_row_body(const int mat, double* __restr
 #pragma unroll
       for (int c = 0; c < W; c++) u[c] = (c >= k) ? s_u[c] : 0.0;
       const double pk = u[k];
-      const double rk = (pk == 0.0 || pk != pk || __builtin_isinf(pk)) ? 1.0 / pk : nd4dpp::fast_rcp(pk);   // 0, Inf, NaN pivots: IEEE semantics
+      // the reciprocal route is used while 1/pivot and the products with it stay far from over/underflow (2^-1000 <= |pivot| <= 2^1000);
+      // zero, denormal, huge, Inf and NaN pivots take the IEEE division of lu.js:68 itself (wave-uniform branch: pk is)
+      const double apk = fabs(pk);
+      const bool fast = apk >= 0x1p-1000 && apk <= 0x1p1000;
+      const double rk = fast ? nd4dpp::fast_rcp(pk) : 0.0;
 #pragma unroll
       for (int i = 0; i < R; i++) {
         if (i > 0 || t > k) {
           // a / pivot (lu.js:68) as a * (1/pivot) with one residual correction: the quotient of a division that comes out
           // exact (integer-valued and structured inputs, where later pivot TIES depend on it) is reproduced exactly, any other
-          // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division
+          // to an ulp; 4 instructions per row instead of the ~15 of an IEEE division. L therefore matches the reference to 1 ulp,
+          // not bit for bit: P is bit-identical on every golden and oracle comparison, but on a NEAR-tie of two candidates whose
+          // values differ in the last bit that identity rests on those comparisons, not on the arithmetic.
           const double q0 = a[i][k] * rk;
-          const double l = fma(fma(-q0, pk, a[i][k]), rk, q0);
+          const double l = fast ? fma(fma(-q0, pk, a[i][k]), rk, q0) : a[i][k] / pk;
           a[i][k] = l;
 #pragma unroll
           for (int c = k + 1; c < W; c++) a[i][c] -= l * u[c];   // lu.js:71-72
@@ -438,7 +444,7 @@ __global__ void lu_iota(int32_t* __restrict__ P, long total, int N) {
 // that a column's loads are independent was tried: 11.0 us per launch against 9.7 us — the kernel is bound by its launch and
 // 8 workgroups of latency, not by the chain.)
 __global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, long strideM, int j0, int nb, const int32_t* __restrict__ ipiv,
-                                                int do_swap, int32_t* __restrict__ Pm) {
+                                                int do_swap, int32_t* __restrict__ Pm, int u12_end) {
   __shared__ double s_l[NB][NB + 1];
   __shared__ int s_piv[NB];
   double* A = LU + blockIdx.y * strideM;
@@ -459,8 +465,9 @@ __global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, 
   }
   int col = blockIdx.x * blockDim.x + t;                   // index among the N - nb outside columns
   if (col >= N - nb) return;
-  const bool right = col >= j0;
+  bool right = col >= j0;
   if (right) col += nb;
+  right = right && col < u12_end;                          // two-level blocking: columns beyond the outer block get the interchanges only
   double x[NB];
 #pragma unroll
   for (int k = 0; k < NB; k++) {                           // swap k: rows j0 + k <-> piv_k; x[k] ends up with row j0 + k
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256) void lu_laswp(double* __restrict__ LU, int N, 
         top = other;
       }
       x[k] = top;
-      if (!right && do_swap && pv != r) A[(long)r * N + col] = top;
+      if (!right && do_swap && pv != r) A[(long)r * N + col] = top;   // (columns without the U12 solve: the row is final as swapped)
     }
   }
   if (!right) return;
@@ -577,37 +584,60 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     ND4_HIP(hipGetLastError());
     j_start = j0;
   }
-  for (int j0 = j_start, step = NB; j0 < N; j0 += step) {
-    const int m = N - j0;
-    // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
-    // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
-    const bool tall8 = m > 2048 && m <= 4096;
-    const bool tall4 = m > 4096 && m <= 8192;
-    step = tall8 ? 8 : tall4 ? 4 : NB;
-    const int nb = N - j0 < step ? N - j0 : step;
-    if (tall8) {
-      launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-    } else if (tall4) {
-      launch_panel_row_wt<8, 4, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-    } else if (m >= 64 && m <= 2048) {
-      if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-    } else {
-      int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
-      hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+  // Two-level blocking for N > 2048 (round 3): with panels of 8 / 4 columns every step used to read-modify-write the whole trailing
+  // matrix (N^3 / (3 NB) * 16 B: 180 GB at 8192^2 for 366 GFLOP). Now an outer block of 256 columns (ND4HIP_LU_OUTER; 128: 4 % slower, 64: 10 %) is factorised by the same
+  // panel kernels with the rank-NB updates restricted to the block (the interchanges still go to every column at once: two rows per
+  // swap), then U12 = L11^-1 A12 for the whole block row (unit lower, the one-launch solver of trsm.hip on a contiguous
+  // copy) and ONE K = 256 product A22 -= L21 U12 on the tiled MFMA kernel. N <= 2048: one level (nbo = N), as before.
+  static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 256; }();
+  const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : N;
+  void* u12buf = nullptr;
+  if (NBO < N) ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NBO * N, &u12buf));
+  for (int J = j_start; J < N; J += NBO) {
+    const int bend = J + NBO < N ? J + NBO : N;               // end of the outer block
+    for (int j0 = J, step = NB; j0 < bend; j0 += step) {
+      const int m = N - j0;
+      // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
+      // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
+      const bool tall8 = m > 2048 && m <= 4096;
+      const bool tall4 = m > 4096 && m <= 8192;
+      step = tall8 ? 8 : tall4 ? 4 : NB;
+      const int nb = bend - j0 < step ? bend - j0 : step;
+      if (tall8) {
+        launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else if (tall4) {
+        launch_panel_row_wt<8, 4, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else if (m >= 64 && m <= 2048) {
+        if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+        else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+        else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else {
+        int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
+        hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+      }
+      const int rest = N - j0 - nb;
+      if (N > nb && (!nopivot || rest > 0))
+        hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                           LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1, p_in_laswp ? P : (int32_t*)nullptr, bend);
+      const int inner = bend - j0 - nb;                        // columns of the block right of the panel
+      if (rest > 0 && inner > 0) {
+        ND4_HIP(hipGetLastError());
+        ND4_TRY(nd4_gemm(h, false, false, rest, inner, nb, -1.0,
+                         LU + (long)(j0 + nb) * N + j0, N, strideM,
+                         LU + (long)j0 * N + j0 + nb, N, strideM,
+                         1.0, LU + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
+      }
     }
-    const int rest = N - j0 - nb;
-    if (N > nb && (!nopivot || rest > 0))
-      hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                         LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1, p_in_laswp ? P : (int32_t*)nullptr);
-    if (rest > 0) {
+    const int far = N - bend, nbo = bend - J;
+    if (far > 0 && NBO < N) {
       ND4_HIP(hipGetLastError());
-      double* base = LU;
-      ND4_TRY(nd4_gemm(h, false, false, rest, rest, nb, -1.0,
-                       base + (long)(j0 + nb) * N + j0, N, strideM,
-                       base + (long)j0 * N + j0 + nb, N, strideM,
-                       1.0, base + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
+      double* U12 = static_cast<double*>(u12buf);
+      const long sU = (long)nbo * far;
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, LU + (long)J * N + bend, N, U12, far, batch, strideM, sU));
+      ND4_TRY(nd4_trsm_ld(h, false, true, batch, nbo, far, LU + (long)J * N + J, N, strideM, U12, sU));
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, U12, far, LU + (long)J * N + bend, N, batch, sU, strideM));
+      ND4_TRY(nd4_gemm(h, false, false, far, far, nbo, -1.0, LU + (long)bend * N + J, N, strideM, U12, far, sU,
+                       1.0, LU + (long)bend * N + bend, N, strideM, batch));
     }
   }
   if (p_in_laswp) { ND4_HIP(hipGetLastError()); return 0; }

@@ -65,8 +65,10 @@ static int (*p_free)(nd4hip_handle*, void*);
 static int (*p_h2d)(nd4hip_handle*, void*, const void*, size_t);
 static int (*p_d2h)(nd4hip_handle*, void*, const void*, size_t);
 static int (*p_sync)(nd4hip_handle*);
+static int (*p_prof_enable)(nd4hip_handle*, int);
+static int (*p_prof_last)(nd4hip_handle*, nd4hip_prof*, int);
 
-static char g_load_error[512] = "";
+static char g_load_error[4608] = "";
 
 static int load_library(void) {
   if (g_lib) return 0;
@@ -120,6 +122,8 @@ static int load_library(void) {
   SYM(p_h2d, "nd4hip_memcpy_h2d");
   SYM(p_d2h, "nd4hip_memcpy_d2h");
   SYM(p_sync, "nd4hip_synchronize");
+  SYM(p_prof_enable, "nd4hip_profile_enable");
+  SYM(p_prof_last, "nd4hip_profile_last");
 #undef SYM
   return 0;
 }
@@ -548,6 +552,37 @@ static void cleanup(void* arg) {
   if (g_handle && p_destroy) { p_destroy(g_handle); g_handle = NULL; }
 }
 
+/* profile_enable(on) */
+static napi_value js_profile_enable(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value a[1]; bool on = true;
+  napi_get_cb_info(env, info, &argc, a, NULL, NULL);
+  if (argc >= 1) napi_get_value_bool(env, a[0], &on);
+  if (ensure_handle(env)) return NULL;
+  if (p_prof_enable(g_handle, on ? 1 : 0) != 0) THROW(env, p_last_error());
+  return NULL;
+}
+/* profile_last() -> [{device, valid, op, kernel_ms, flops, bytes}] : one record per device of the handle (nd4hip_profile_last) */
+static napi_value js_profile_last(napi_env env, napi_callback_info info) {
+  (void)info;
+  if (ensure_handle(env)) return NULL;
+  nd4hip_prof rec[64];
+  const int n = p_prof_last(g_handle, rec, 64);
+  if (n < 0) THROW(env, p_last_error());
+  napi_value arr, o, v;
+  napi_create_array_with_length(env, (size_t)n, &arr);
+  for (int i = 0; i < n && i < 64; i++) {
+    napi_create_object(env, &o);
+    napi_create_int32(env, rec[i].device, &v); napi_set_named_property(env, o, "device", v);
+    napi_get_boolean(env, rec[i].valid != 0, &v); napi_set_named_property(env, o, "valid", v);
+    napi_create_string_utf8(env, rec[i].op, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "op", v);
+    napi_create_double(env, rec[i].kernel_ms, &v); napi_set_named_property(env, o, "kernel_ms", v);
+    napi_create_double(env, rec[i].flops, &v); napi_set_named_property(env, o, "flops", v);
+    napi_create_double(env, rec[i].bytes, &v); napi_set_named_property(env, o, "bytes", v);
+    napi_set_element(env, arr, (uint32_t)i, o);
+  }
+  return arr;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
     {"device_count", NULL, js_device_count, NULL, NULL, NULL, napi_default, NULL},
@@ -574,6 +609,8 @@ static napi_value init(napi_env env, napi_value exports) {
     {"dev_upload", NULL, js_dev_upload, NULL, NULL, NULL, napi_default, NULL},
     {"dev_download", NULL, js_dev_download, NULL, NULL, NULL, napi_default, NULL},
     {"synchronize", NULL, js_synchronize, NULL, NULL, NULL, napi_default, NULL},
+    {"profile_enable", NULL, js_profile_enable, NULL, NULL, NULL, napi_default, NULL},
+    {"profile_last", NULL, js_profile_last, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   napi_add_env_cleanup_hook(env, cleanup, NULL);

@@ -12,6 +12,16 @@ constexpr size_t D = sizeof(double);
 constexpr int64_t ND4_CHUNK = 32768;
 #define ND4_FOR_CHUNKS(batch) for (int64_t b0 = 0, nb = 0; (nb = ((batch) - b0 < ND4_CHUNK ? (batch) - b0 : ND4_CHUNK)) > 0; b0 += nb)
 
+// algorithmic flop conventions of SURVEY.md 8(d) for nd4hip_profile_last
+inline double nd4_flops_qr(int64_t M, int64_t N) {          // with explicit Q: 4 (M N^2 - N^3 / 3) for M >= N, 8/3 N^3 when square
+  const double m = (double)M, n = (double)N;
+  return M >= N ? 4.0 * (m * n * n - n * n * n / 3.0) : 2.0 * n * m * m - 2.0 / 3.0 * m * m * m + 4.0 / 3.0 * m * m * m;
+}
+inline double nd4_flops_svd(int64_t M, int64_t N) {         // Golub-Reinsch count with U, sv, V: 21 N^3 when square
+  const double m = (double)(M >= N ? M : N), n = (double)(M >= N ? N : M);
+  return 4.0 * m * m * n + 8.0 * m * n * n + 9.0 * n * n * n;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ matmul
@@ -19,6 +29,7 @@ extern "C" int nd4hip_dgemm_batched_dev(nd4hip_handle* h, int64_t batch, int64_t
                                         const double* A, int64_t strideA, const double* B, int64_t strideB, double* C) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgemm_batched", (double)(2.0 * batch * I * K * J), (double)(8.0 * (double)(batch * I * J + (strideA ? batch : 1) * I * K + (strideB ? batch : 1) * K * J)));
   ND4_CHECK_ARG(batch >= 0 && I >= 0 && K >= 0 && J >= 0, "nd4hip_dgemm_batched: negative extent");
   ND4_CHECK_ARG(strideA == 0 || strideA >= I * K, "nd4hip_dgemm_batched: strideA must be 0 or >= I*K");
   ND4_CHECK_ARG(strideB == 0 || strideB >= K * J, "nd4hip_dgemm_batched: strideB must be 0 or >= K*J");
@@ -38,6 +49,7 @@ extern "C" int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int
                                    double beta, double* C, int64_t ldc) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgemm_ex: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgemm_ex", (double)(2.0 * M * N * K), (double)(8.0 * (double)(M * K + K * N + M * N)));
   ND4_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "nd4hip_dgemm_ex: negative extent");
   ND4_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "nd4hip_dgemm_ex: leading dimension too small");
   if (M == 0 || N == 0) return 0;
@@ -48,6 +60,7 @@ extern "C" int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int
 extern "C" int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrf_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgetrf_batched", (double)(2.0 / 3.0 * batch * N * N * N), (double)(16.0 * batch * N * N));
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgetrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && LU && P, "nd4hip_dgetrf_batched: NULL pointer");
@@ -67,6 +80,7 @@ extern "C" int nd4hip_dgetrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                                          const int32_t* P, int64_t strideP, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgetrs_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgetrs_batched", (double)(2.0 * batch * N * N * J), (double)(8.0 * batch * (double)(N * N + 2 * N * J)));
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dgetrs_batched: negative extent");
   ND4_CHECK_ARG((strideLU == 0 || strideLU >= N * N) && (strideP == 0 || strideP >= N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dgetrs_batched: a stride must be 0 or at least the size of one operand");
@@ -80,6 +94,7 @@ extern "C" int nd4hip_dtrsm_batched_dev(nd4hip_handle* h, int upper, int unit_di
                                         const double* T, int64_t strideT, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dtrsm_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dtrsm_batched", (double)(1.0 * batch * M * M * J), (double)(8.0 * batch * (double)(M * M / 2 + 2 * M * J)));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && J >= 0, "nd4hip_dtrsm_batched: negative extent");
   ND4_CHECK_ARG((strideT == 0 || strideT >= M * M) && (strideY == 0 || strideY >= M * J),
                 "nd4hip_dtrsm_batched: a stride must be 0 or at least the size of one operand");
@@ -96,6 +111,7 @@ extern "C" int nd4hip_dqrls_batched_dev(nd4hip_handle* h, int64_t batch, int64_t
                                         const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dqrls_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dqrls_batched", (double)(0.0), (double)(0.0));
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dqrls_batched: negative extent");
   ND4_CHECK_ARG(I <= N, "qr_lstsq(Q,R,y): Under-determined systems not supported. Use rrqr instead.");      // qr.js:209
   ND4_CHECK_ARG((strideQ == 0 || strideQ >= N * M) && (strideR == 0 || strideR >= M * I) && (strideY == 0 || strideY >= N * J),
@@ -113,6 +129,7 @@ extern "C" int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                                          const double* V, int64_t strideV, const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dsvdls_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dsvdls_batched", (double)(0.0), (double)(0.0));
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && M >= 0 && I >= 0 && J >= 0, "nd4hip_dsvdls_batched: negative extent");
   ND4_CHECK_ARG((strideU == 0 || strideU >= N * M) && (strideSv == 0 || strideSv >= M) && (strideV == 0 || strideV >= M * I) &&
                 (strideY == 0 || strideY >= N * J), "nd4hip_dsvdls_batched: a stride must be 0 or at least the size of one operand");
@@ -129,6 +146,7 @@ extern "C" int nd4hip_dsvdls_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dpotrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* L) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrf_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dpotrf_batched", (double)(batch * N * N * N / 3.0), (double)(16.0 * batch * N * N));
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dpotrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(S && L, "nd4hip_dpotrf_batched: NULL pointer");
@@ -151,6 +169,7 @@ extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
                                          const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dpotrs_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dpotrs_batched", (double)(2.0 * batch * N * N * J), (double)(8.0 * batch * (double)(N * N + 2 * N * J)));
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dpotrs_batched: negative extent");
   ND4_CHECK_ARG((strideL == 0 || strideL >= N * N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dpotrs_batched: a stride must be 0 or at least the size of one operand");
@@ -164,6 +183,7 @@ extern "C" int nd4hip_dpotrs_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dldltrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* S, double* LD) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrf_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dldltrf_batched", (double)(batch * N * N * N / 3.0), (double)(16.0 * batch * N * N));
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dldltrf_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(S && LD, "nd4hip_dldltrf_batched: NULL pointer");
@@ -174,6 +194,7 @@ extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64
                                           const double* Y, int64_t strideY, double* X) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dldltrs_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dldltrs_batched", (double)(2.0 * batch * N * N * J), (double)(8.0 * batch * (double)(N * N + 2 * N * J)));
   ND4_CHECK_ARG(batch >= 0 && N >= 0 && J >= 0, "nd4hip_dldltrs_batched: negative extent");
   ND4_CHECK_ARG((strideLD == 0 || strideLD >= N * N) && (strideY == 0 || strideY >= N * J),
                 "nd4hip_dldltrs_batched: a stride must be 0 or at least the size of one operand");
@@ -187,6 +208,7 @@ extern "C" int nd4hip_dldltrs_batched_dev(nd4hip_handle* h, int64_t batch, int64
 extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgebrd_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgebrd_batched", (double)(batch * nd4_flops_qr(M, N)), (double)(8.0 * batch * (double)(2 * M * N + M * M + N * N)));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgebrd_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && B && V, "nd4hip_dgebrd_batched: NULL pointer");
@@ -199,6 +221,7 @@ extern "C" int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgehrd_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgehrd_batched", (double)(14.0 / 3.0 * batch * N * N * N), (double)(24.0 * batch * N * N));
   ND4_CHECK_ARG(batch >= 0 && N >= 0, "nd4hip_dgehrd_batched: negative extent");
   if (batch == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && U && H, "nd4hip_dgehrd_batched: NULL pointer");
@@ -210,6 +233,7 @@ extern "C" int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_
 extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_q_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgeqrf_q_batched", (double)(batch * nd4_flops_qr(M, N)), (double)(8.0 * batch * (double)(M * N + (M + N) * (M < N ? M : N))));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_q_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_q_batched: NULL pointer");
@@ -222,6 +246,7 @@ extern "C" int nd4hip_dgeqrf_q_batched_dev(nd4hip_handle* h, int64_t batch, int6
 extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_full_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgeqrf_full_batched", (double)(batch * nd4_flops_qr(M, N)), (double)(8.0 * batch * (double)(2 * M * N + M * M)));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgeqrf_full_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && Q && R, "nd4hip_dgeqrf_full_batched: NULL pointer");
@@ -233,6 +258,7 @@ extern "C" int nd4hip_dgeqrf_full_batched_dev(nd4hip_handle* h, int64_t batch, i
 extern "C" int nd4hip_dgeqrf_qty_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, int64_t L, double* A, double* Y) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqrf_qty_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgeqrf_qty_batched", (double)(batch * nd4_flops_qr(M, N)), (double)(16.0 * batch * (double)(M * N + M * L)));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0 && L >= 0, "nd4hip_dgeqrf_qty_batched: negative extent");
   if (batch == 0 || M == 0 || N == 0) return 0;
   ND4_CHECK_ARG(A && (Y || L == 0), "nd4hip_dgeqrf_qty_batched: NULL pointer");
@@ -256,6 +282,7 @@ extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64
                                           double* U, double* sv, double* V, int* sweeps_out, double* offnorm_out) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgesvdj_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgesvdj_batched", (double)(batch * nd4_flops_svd(M, N)), (double)(8.0 * batch * (double)(M * N + (M + N + 1) * (M < N ? M : N))));
   ND4_CHECK_ARG(batch >= 0 && M >= 0 && N >= 0, "nd4hip_dgesvdj_batched: negative extent");
   if (sweeps_out) *sweeps_out = 0;
   if (offnorm_out) *offnorm_out = 0.0;
@@ -281,6 +308,7 @@ extern "C" int nd4hip_dgesvdj_batched_dev(nd4hip_handle* h, int64_t batch, int64
 extern "C" int nd4hip_dgeqr2_panel_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t b, double* A, double* V, double* T) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_dgeqr2_panel_batched: NULL handle");
   Nd4DeviceGuard guard(h);
+  Nd4Prof prof(h, "dgeqr2_panel_batched", (double)(2.0 * batch * M * b * b), (double)(16.0 * batch * M * b));
   ND4_CHECK_ARG(b == 16, "nd4hip_dgeqr2_panel_batched: the panel width is 16");
   ND4_CHECK_ARG(batch >= 0 && batch <= 65535 && M >= 1 && M <= 2048, "nd4hip_dgeqr2_panel_batched: 1 <= M <= 2048 rows, batch <= 65535");
   if (batch == 0) return 0;

@@ -40,6 +40,8 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_p0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_p1);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     e = hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming);
@@ -67,6 +69,8 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+  if (h->ev_p0) (void)hipEventDestroy(h->ev_p0);
+  if (h->ev_p1) (void)hipEventDestroy(h->ev_p1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -79,8 +83,15 @@ extern "C" int nd4hip_set_stream(nd4hip_handle* h, void* s) {
     // the workspace arena (and cached staging) is reused in stream order: work queued on the new stream must not start
     // before what the old stream still has in flight on those blocks
     Nd4DeviceGuard guard(h);
-    ND4_HIP(hipEventRecord(h->ev_order, h->stream));
-    ND4_HIP(hipStreamWaitEvent(next, h->ev_order, 0));
+    // (the previous stream must still be alive here; if the caller has already destroyed it the record fails: order by a device
+    //  synchronisation instead and switch anyway, so that the handle does not stay on a dead stream)
+    if (hipEventRecord(h->ev_order, h->stream) == hipSuccess) {
+      ND4_HIP(hipStreamWaitEvent(next, h->ev_order, 0));
+    } else {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+    }
     h->stream = next;
   }
   return 0;
@@ -173,6 +184,45 @@ extern "C" int nd4hip_memcpy_d2h(nd4hip_handle* h, void* d, const void* s, size_
   if (bytes) ND4_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
   ND4_HIP(hipStreamSynchronize(h->stream));
   return 0;
+}
+
+Nd4Prof::Nd4Prof(nd4hip_handle* hh, const char* op, double flops, double bytes) : h(hh), active(false) {
+  if (!h || !h->prof_on) return;
+  if (h->prof_depth++ > 0) return;                       // an entry point called from another one
+  active = true;
+  h->prof_flops = flops; h->prof_bytes = bytes; h->prof_valid = false;
+  snprintf(h->prof_op, sizeof h->prof_op, "%s", op);
+  (void)hipEventRecord(h->ev_p0, h->stream);
+}
+Nd4Prof::~Nd4Prof() {
+  if (!h || !h->prof_on) return;
+  if (h->prof_depth > 0) h->prof_depth--;
+  if (!active) return;
+  h->prof_valid = hipEventRecord(h->ev_p1, h->stream) == hipSuccess;
+}
+extern "C" int nd4hip_profile_enable(nd4hip_handle* h, int on) {
+  ND4_CHECK_ARG(h != nullptr, "nd4hip_profile_enable: NULL handle");
+  h->prof_on = on != 0; h->prof_depth = 0; if (!on) h->prof_valid = false;
+  for (nd4hip_handle* p : h->peers) { p->prof_on = on != 0; p->prof_depth = 0; if (!on) p->prof_valid = false; }
+  return 0;
+}
+extern "C" int nd4hip_profile_last(nd4hip_handle* h, nd4hip_prof* out, int capacity) {
+  ND4_CHECK_ARG(h != nullptr && (out != nullptr || capacity == 0), "nd4hip_profile_last: NULL argument");
+  const int n = 1 + (int)h->peers.size();
+  for (int i = 0; i < n && i < capacity; i++) {
+    nd4hip_handle* d = i == 0 ? h : h->peers[(size_t)i - 1];
+    nd4hip_prof& r = out[i];
+    memset(&r, 0, sizeof r);
+    r.device = d->device;
+    if (!d->prof_valid) continue;
+    Nd4DeviceGuard guard(d);
+    float ms = 0.0f;
+    ND4_HIP(hipEventSynchronize(d->ev_p1));
+    ND4_HIP(hipEventElapsedTime(&ms, d->ev_p0, d->ev_p1));
+    r.kernel_ms = ms; r.flops = d->prof_flops; r.bytes = d->prof_bytes; r.valid = 1;
+    snprintf(r.op, sizeof r.op, "%s", d->prof_op);
+  }
+  return n;
 }
 
 extern "C" int nd4hip_timer_start(nd4hip_handle* h) {

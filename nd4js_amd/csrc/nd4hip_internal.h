@@ -28,6 +28,8 @@ struct nd4hip_handle {
   int num_cu = 256;
   unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)
   int svd_sweeps = 0; unsigned long long svd_rotations = 0; double svd_offnorm = 0.0;   // audit of the last SVD call
+  bool prof_on = false, prof_valid = false; int prof_depth = 0;                          // nd4hip_profile_enable / _last
+  hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr; double prof_flops = 0.0, prof_bytes = 0.0; char prof_op[32] = "";
 };
 
 // Makes h->device the calling thread's current HIP device for the duration of an entry point and restores the previous
@@ -41,6 +43,15 @@ struct Nd4DeviceGuard {
   ~Nd4DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
   Nd4DeviceGuard(const Nd4DeviceGuard&) = delete;
   Nd4DeviceGuard& operator=(const Nd4DeviceGuard&) = delete;
+};
+
+// brackets the kernels of one entry point with the handle's profile events (outermost entry point only: QR inside SVD does not count)
+struct Nd4Prof {
+  nd4hip_handle* h; bool active;
+  Nd4Prof(nd4hip_handle* hh, const char* op, double flops, double bytes);
+  ~Nd4Prof();
+  Nd4Prof(const Nd4Prof&) = delete;
+  Nd4Prof& operator=(const Nd4Prof&) = delete;
 };
 
 void nd4_set_error(const char* fmt, ...);

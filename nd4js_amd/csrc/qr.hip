@@ -32,7 +32,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NB = 16;
-constexpr int RMAX = 48;
+constexpr int RMAX = 48;   // (slots per lane group of the global-memory fallback panel)
+[[maybe_unused]] constexpr int RMAX_USED = RMAX;
 constexpr int VTC_ROWS = 256;     // rows per workgroup of qr_vtc
 constexpr int VTC_COLS = 64;      // columns per workgroup of qr_vtc
 
@@ -65,10 +66,10 @@ struct Slots {
 };
 
 template <int R, bool REG>
-__global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M, long ld, long strideW,
-                                                   double* __restrict__ Vall, long ldv, long strideV,
-                                                   double* __restrict__ Tall, long strideT,
-                                                   double* __restrict__ taus, long strideTau, int j0, int nb) {
+__device__ __forceinline__ void qr_panel_body(double* __restrict__ Wm, int M, long ld, long strideW,
+                                              double* __restrict__ Vall, long ldv, long strideV,
+                                              double* __restrict__ Tall, long strideT,
+                                              double* __restrict__ taus, long strideTau, int j0, int nb) {
   __shared__ double s_red[16];
   __shared__ double s_w[16][NB];
   __shared__ double s_T[NB][NB + 1];
@@ -197,6 +198,23 @@ __global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M,
     const int i = t / NB, j = t % NB;
     Tall[blockIdx.x * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
   }
+}
+
+template <int R, bool REG>
+__global__ __launch_bounds__(1024) void qr_panel(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                   double* __restrict__ Vall, long ldv, long strideV,
+                                                   double* __restrict__ Tall, long strideT,
+                                                   double* __restrict__ taus, long strideTau, int j0, int nb) {
+  qr_panel_body<R, REG>(Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
+}
+// the same panel, only for the matrices whose flag is set: the fall-back of a multi-workgroup panel taller than the register-resident
+// kernel holds (m > 2048), as a launch of its own behind phase C (two short launches that do nothing in the common case)
+__global__ __launch_bounds__(1024) void qr_panel_flagged(double* __restrict__ Wm, int M, long ld, long strideW,
+                                                          double* __restrict__ Vall, long ldv, long strideV,
+                                                          double* __restrict__ Tall, long strideT,
+                                                          double* __restrict__ taus, long strideTau, int j0, int nb, const int* __restrict__ flag) {
+  if (!flag[blockIdx.x]) return;
+  qr_panel_body<1, false>(Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
 }
 
 // ---- thread-per-row panel kernel (m <= 2048): each of 512 threads keeps R whole panel rows in registers ----
@@ -645,6 +663,7 @@ struct QrhP {
   int ngp;                          // Gram partials to sum (phase B: phase A's row workgroups; phase C: phase B's)
   int wide0, nnw, nrc;              // side work (reflector pj0): nnw column blocks of W from wide0 on (then blocks of Q^T), nrc row chunks each
   int nseg; QrhSeg seg[2];          // the side work of this launch: workgroups nrow.. walk these segments
+  int skip_x;                       // phase C: no partial X for the next panel (last panel of an outer block: the block update covers it)
   long long* stamps; int stamp_slot; // debug (ND4HIP_QR_STAMPS): 100 MHz wall-clock stamps of workgroup 0, 8 per launch
 };
 
@@ -1038,11 +1057,12 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   double* A = P.Wm + mat * P.strideW;
   const int j0 = P.j0, M = P.M, N = P.N;
   const long ld = P.ld;
-  const int c0 = j0 + NB, nc = N - c0 < NB ? N - c0 : NB;             // the next panel's columns (nc <= 0: none)
+  const int c0 = j0 + NB, nc = P.skip_x ? 0 : (N - c0 < NB ? N - c0 : NB);   // the next panel's columns (nc <= 0: none)
   double* Xdst = P.Xp + mat * P.strideXp + (long)g * 256;
   if (P.flag[mat]) {
-    if (g == 0) {
-      qr_panel_row_body<R>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
+    if constexpr (R == 0) return;                                      // tall panel: qr_panel_flagged + qrh_x_flagged follow
+    else if (g == 0) {
+      qr_panel_row_body<(R > 0 ? R : 1)>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
       __threadfence();
       __syncthreads();
       if (nc > 0) qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)j0 * P.ldv + j0, P.ldv, A + (long)j0 * ld + c0, ld, M - j0, nc, Xdst);
@@ -1176,6 +1196,18 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   }
   qrh_stamp(P, 5);
   qrh_stamp(P, 6);
+}
+
+// partials of X = V^T C for the next panel's columns after qr_panel_flagged (workgroup 0: all rows; the others: zero)
+__global__ __launch_bounds__(512) void qrh_x_flagged(const QrhP P) {
+  __shared__ double s_buf[QRH_LDS];
+  const int mat = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  if (!P.flag[mat]) return;
+  const int j0 = P.j0, c0 = j0 + NB, nc = P.N - c0 < NB ? P.N - c0 : NB;
+  if (nc <= 0) return;
+  double* Xdst = P.Xp + mat * P.strideXp + (long)g * 256;
+  if (g == 0) qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)j0 * P.ldv + j0, P.ldv, P.Wm + mat * P.strideW + (long)j0 * P.ld + c0, P.ld, P.M - j0, nc, Xdst);
+  else if (t < 256) Xdst[t] = 0.0;
 }
 
 // ---- the same panel kernel for taller panels: 1024 threads leave 128 VGPRs per lane = R rows of W columns with R * W = 32:
@@ -1594,7 +1626,86 @@ int form_q_compact_wy(nd4hip_handle* h, const QrWs& ws, int batch, int M, int Lq
   return 0;
 }
 
+
+// host side of the multi-workgroup panels: one panel = three launches (+ two conditional ones for panels taller than the register
+// kernel), the previous reflector's side work riding along on the column blocks of W up to near_end (then, optionally, Q^T)
+struct QrhHost {
+  nd4hip_handle* h; QrhP P; int batch; int nq;          // nq: column blocks of Q^T (0: no Q^T accumulation)
+  double *V, *T; long ldv, sV, sT;                        // for qr_narrow_apply
+  int pj0 = -1;                                           // the reflector whose narrow / side work is pending (-1: none)
+  void add_seg(int kind, int first, int count) { if (count > 0) { P.seg[P.nseg].kind = kind; P.seg[P.nseg].first = first; P.seg[P.nseg].count = count; P.nseg++; } }
+  int seg_total() const { int n = 0; for (int i = 0; i < P.nseg; i++) n += P.seg[i].count; return n; }
+  void side_launch() { if (P.nseg > 0) hipLaunchKernelGGL(qrh_side_only, dim3((unsigned)seg_total(), (unsigned)batch), dim3(512), 0, h->stream, P); P.nseg = 0; }
+  // the side work of the reflector at pj: workgroups for W (columns [pj + 32, near_end)), for W and Q^T
+  void side_of(int pj, int near_end, bool with_qt, int& nw_e, int& all_e) {
+    nw_e = 0; all_e = 0;
+    if (pj < 0) return;
+    const int wide0 = pj + 2 * NB;
+    P.wide0 = wide0; P.nrc = (P.M - pj + 511) / 512;
+    P.nnw = wide0 < near_end ? (near_end - wide0 + NB - 1) / NB : 0;
+    nw_e = P.nnw * P.nrc; all_e = nw_e + (with_qt ? nq * P.nrc : 0);
+  }
+  int panel(int j0, int near_end, bool with_qt, bool skip_x) {
+    const int m = P.M - j0;
+    int side_w = 0, side_all = 0;
+    side_of(pj0, near_end, with_qt, side_w, side_all);
+    P.j0 = j0; P.pj0 = pj0; P.skip_x = skip_x ? 1 : 0;
+    const int nA = (m + NB + 511) / 512, nB = (m + 511) / 512;
+    P.nrow = nA; P.ngp = 0; P.nseg = 0; add_seg(SEG_NX, 0, side_all);
+    hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+    P.nrow = nB; P.ngp = nA; P.nseg = 0; add_seg(SEG_NA, 0, side_w);
+    hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+    P.ngp = nB; P.nseg = 0; add_seg(SEG_NA, side_w, side_all - side_w);
+    const dim3 gc((unsigned)(nB + seg_total()), (unsigned)batch);
+    if (m <= 512)       hipLaunchKernelGGL(qrh_reconstruct<1>, gc, dim3(512), 0, h->stream, P);
+    else if (m <= 1024) hipLaunchKernelGGL(qrh_reconstruct<2>, gc, dim3(512), 0, h->stream, P);
+    else if (m <= 2048) hipLaunchKernelGGL(qrh_reconstruct<4>, gc, dim3(512), 0, h->stream, P);
+    else {
+      // taller than the register-resident panel: a flagged panel is factorised by the global-memory panel kernel in a launch of its own
+      hipLaunchKernelGGL(qrh_reconstruct<0>, gc, dim3(512), 0, h->stream, P);
+      hipLaunchKernelGGL(qr_panel_flagged, dim3((unsigned)batch), dim3(1024), 0, h->stream, P.Wm, P.M, P.ld, P.strideW, P.Vall, P.ldv, P.strideV,
+                         P.Tall, P.strideT, P.taus, P.strideTau, j0, NB, P.flag);
+      if (!skip_x) hipLaunchKernelGGL(qrh_x_flagged, dim3((unsigned)nB, (unsigned)batch), dim3(512), 0, h->stream, P);
+    }
+    pj0 = j0; P.nxp = nB; P.nseg = 0; P.stamp_slot++;
+    ND4_HIP(hipGetLastError());
+    return 0;
+  }
+  // the last reflector: the 16 columns behind its panel (unless the caller's block update covers them), then its side work on its own
+  int finish(int near_end, bool with_qt, bool narrow) {
+    if (pj0 < 0) return 0;
+    if (narrow && pj0 + NB < P.N) {
+      const int m = P.M - pj0;
+      hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                         P.Wm, P.M, P.N, P.ld, P.strideW, V, ldv, sV, T, sT, pj0, pj0 + NB, P.Xp, P.strideXp, P.nxp);
+    }
+    int side_w = 0, side_all = 0;
+    side_of(pj0, near_end, with_qt, side_w, side_all);
+    P.pj0 = pj0;
+    P.nseg = 0; add_seg(SEG_NX, 0, side_all); side_launch();
+    add_seg(SEG_NA, 0, side_all); side_launch();
+    pj0 = -1;
+    ND4_HIP(hipGetLastError());
+    return 0;
+  }
+  int dump_stamps() {                                      // debug: per launch, the stamps of workgroup 0 relative to the first one, in us
+    if (!P.stamps) return 0;
+    std::vector<long long> st((size_t)8 * P.stamp_slot);
+    ND4_HIP(hipStreamSynchronize(h->stream));
+    ND4_HIP(hipMemcpy(st.data(), P.stamps, sizeof(long long) * st.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(P.stamps); P.stamps = nullptr;
+    for (int i = 0; i < P.stamp_slot; i++) {
+      fprintf(stderr, "qrh stamp launch %d (%c panel %d):", i, "ABC"[i % 3], i / 3);
+      for (int k = 0; k < 8; k++) fprintf(stderr, " %.2f", st[i * 8 + k] ? (st[i * 8 + k] - st[0]) * 0.01 : 0.0);
+      fprintf(stderr, "\n");
+    }
+    return 0;
+  }
+};
+
 }  // namespace
+
+static int wy_build_T(nd4hip_handle* h, int M, int n, const double* V, long ldv, const double* Tdiag, int bs, double* Tall, double* G, double* tmp);
 
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
   return nd4_geqrf_q_ex(h, batch, M, N, A, Q, R, false);
@@ -1673,7 +1784,9 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   const bool use_qt = lookahead && !wy_off && !qt_off && batch <= 4 && L >= 256;   // Q^T accumulated in the shadow of the panels
   const long sQT = use_qt ? (long)M * M : 0;
   static const bool hr_off = [] { const char* e = getenv("ND4HIP_QR_NO_HR"); return e && *e && *e != '0'; }();
-  const bool use_hr = lookahead && !hr_off && batch <= 8;    // multi-workgroup panels (CholeskyQR2 + compact orthogonal completion)
+  // panels taller than the register kernel: two-level driver below (a ragged last panel must fit the thread-per-row kernel)
+  const bool hr_tall = !hr_off && !la_off && batch <= 8 && M > 2048 && M <= 16384 && L >= 256 && (L % NB == 0 || M - (L / NB) * NB <= 2048);
+  const bool use_hr = (lookahead && !hr_off && batch <= 8) || hr_tall;    // multi-workgroup panels (CholeskyQR2 + compact orthogonal completion)
   const int hr_parts = (M + NB + 511) / 512 + 1;
   const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 256 : 0, sR1 = use_hr ? 256 : 0;
   const long hr_rcs = (M + 511) / 512;
@@ -1715,6 +1828,19 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   // ---- factorisation: panels left to right ----
   // Look-ahead form (every panel fits the thread-per-row kernel): panel p shares its launch with the update of the columns behind
   // it by reflector p-1; only the 16 columns of panel p+1 are updated between two panels. See qr_colblock_update.
+  static const int hr_min_rows = [] { const char* e = getenv("ND4HIP_QR_HR_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= HR_MIN_ROWS ? v : HR_MIN_ROWS; }();
+  QrhHost hr;
+  hr.h = h; hr.batch = batch; hr.nq = QT ? (M + NB - 1) / NB : 0; hr.V = ws.V; hr.T = ws.T; hr.ldv = ws.ldv; hr.sV = ws.sV; hr.sT = ws.sT;
+  if (use_hr) {
+    QrhP& P = hr.P;
+    P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
+    P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
+    P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
+    P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.skip_x = 0; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
+    static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
+    P.stamps = nullptr; P.stamp_slot = 0;
+    if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
+  }
   if (lookahead) {
     int pj0 = -1;                                            // first row/column of the previous panel
     const int nq = QT ? (M + NB - 1) / NB : 0;
@@ -1724,70 +1850,13 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
       // multi-workgroup panels while they are full and tall enough: three launches per panel (Gram / Cholesky / representation). The
       // previous reflector's side work rides along: partial X of every column block (trailing columns of W, then Q^T) in launch A,
       // the update of the blocks of W in launch B (phase C reads the first of them), of Q^T in launch C.
-      QrhP P;
-      P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
-      P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
-      P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
-      P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0;
-      static const int hr_min_rows = [] { const char* e = getenv("ND4HIP_QR_HR_MIN_ROWS"); const int v = e ? atoi(e) : 0; return v >= HR_MIN_ROWS ? v : HR_MIN_ROWS; }();
-      static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
-      P.stamps = nullptr; P.stamp_slot = 0;
-      if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
-      auto add_seg = [&](int kind, int first, int count) { if (count > 0) { P.seg[P.nseg].kind = kind; P.seg[P.nseg].first = first; P.seg[P.nseg].count = count; P.nseg++; } };
-      auto seg_total = [&]() { int n = 0; for (int i = 0; i < P.nseg; i++) n += P.seg[i].count; return n; };
-      auto side_launch = [&]() { if (P.nseg > 0) hipLaunchKernelGGL(qrh_side_only, dim3((unsigned)seg_total(), (unsigned)batch), dim3(512), 0, h->stream, P); P.nseg = 0; };
-      auto side_of = [&](int pj, int& nw_e, int& all_e) {      // the side work of the reflector at pj: workgroups for W, for W and Q^T
-        nw_e = 0; all_e = 0;
-        if (pj < 0) return;
-        const int wide0 = pj + 2 * NB;
-        P.wide0 = wide0; P.nrc = (M - pj + 511) / 512;
-        P.nnw = wide0 < N ? (N - wide0 + NB - 1) / NB : 0;
-        nw_e = P.nnw * P.nrc; all_e = nw_e + nq * P.nrc;
-      };
       for (; pnl < npanels; pnl++) {
         const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
         if (nb < NB || m < hr_min_rows) break;
-        int side_w = 0, side_all = 0;
-        side_of(pj0, side_w, side_all);
-        P.j0 = j0; P.pj0 = pj0;
-        const int nA = (m + NB + 511) / 512, nB = (m + 511) / 512;
-        P.nrow = nA; P.ngp = 0; P.nseg = 0; add_seg(SEG_NX, 0, side_all);
-        hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
-        P.nrow = nB; P.ngp = nA; P.nseg = 0; add_seg(SEG_NA, 0, side_w);
-        hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
-        P.ngp = nB; P.nseg = 0; add_seg(SEG_NA, side_w, side_all - side_w);
-        const dim3 gc((unsigned)(nB + seg_total()), (unsigned)batch);
-        if (m <= 512)       hipLaunchKernelGGL(qrh_reconstruct<1>, gc, dim3(512), 0, h->stream, P);
-        else if (m <= 1024) hipLaunchKernelGGL(qrh_reconstruct<2>, gc, dim3(512), 0, h->stream, P);
-        else                hipLaunchKernelGGL(qrh_reconstruct<4>, gc, dim3(512), 0, h->stream, P);
-        pj0 = j0; P.nxp = nB; P.nseg = 0; P.stamp_slot++;
+        ND4_TRY(hr.panel(j0, N, QT != nullptr, false));
       }
-      if (pj0 >= 0) {
-        // the last such reflector: the 16 columns behind its panel, then its side work on its own
-        if (pj0 + NB < N) {
-          const int m = M - pj0;
-          hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                             W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, pj0, pj0 + NB, ws.Wp, ws.sWb, P.nxp);
-        }
-        int side_w = 0, side_all = 0;
-        side_of(pj0, side_w, side_all);
-        P.pj0 = pj0;
-        P.nseg = 0; add_seg(SEG_NX, 0, side_all); side_launch();
-        add_seg(SEG_NA, 0, side_all); side_launch();
-        pj0 = -1;                                              // nothing pending: the remaining panels start afresh
-      }
-      if (P.stamps) {                                          // debug: per launch, the stamps of workgroup 0 relative to the first one, in us
-        std::vector<long long> st((size_t)8 * P.stamp_slot);
-        ND4_HIP(hipStreamSynchronize(h->stream));
-        ND4_HIP(hipMemcpy(st.data(), P.stamps, sizeof(long long) * st.size(), hipMemcpyDeviceToHost));
-        (void)hipFree(P.stamps);
-        for (int i = 0; i < P.stamp_slot; i++) {
-          fprintf(stderr, "qrh stamp launch %d (%c panel %d):", i, "ABC"[i % 3], i / 3);
-          for (int k = 0; k < 8; k++) fprintf(stderr, " %.2f", st[i * 8 + k] ? (st[i * 8 + k] - st[0]) * 0.01 : 0.0);
-          fprintf(stderr, "\n");
-        }
-      }
-      ND4_HIP(hipGetLastError());
+      ND4_TRY(hr.finish(N, QT != nullptr, true));             // nothing pending afterwards: the remaining panels start afresh
+      ND4_TRY(hr.dump_stamps());
     }
     for (; pnl < npanels; pnl++) {
       const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
@@ -1815,8 +1884,124 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
                                  QT, M, M, (long)M, sQT, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, (npanels - 1) * NB, 0);
     }
     ND4_HIP(hipGetLastError());
-  } else
-  for (int pnl = 0; pnl < npanels; pnl++) {
+  } else if (hr_tall) {
+    // ---- M > 2048, two levels with multi-workgroup panels (round 3) ----
+    // The split register panels (two 8-column halves / four 4-column quarters per 16-column slot, each followed by its own
+    // block-reflector launches and a Gram product) took ~165 us per slot, and every slot read-modify-wrote the whole trailing
+    // matrix. Now: outer blocks of 128 columns; inside a block the row-split panels of qrh_* (no height limit: the rows are cut into
+    // 512-row workgroups) with the previous reflector riding along on the block's own columns only; after the block its compact-WY
+    // factor T (128 x 128: the panels' 16 x 16 factors on the diagonal, T12 = -T1 (V1^T V2) T2 level by level from one Gram matrix)
+    // takes all 128 reflectors to the columns right of it at once on the tiled MFMA kernel: X = V^T C, W = T^T X, C -= V W (K = 128).
+    // Once the panels fit the register kernel (m <= 2048) the rest is factorised with one level, as a 2048-row problem. Q is formed
+    // afterwards by applying the same block reflectors backwards (4/3 M^3 flop instead of the 6 M n^2 of the one-shot formation).
+    const int ppb = 128 / NB;
+    const size_t nbo = 128, nblocks = (size_t)(npanels + ppb - 1) / ppb;
+    void* q = nullptr;
+    const int ncq = N > Lq ? N : Lq;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (nblocks * nbo * nbo + nbo * nbo * 2 + nbo * nbo / 2 + 16 + 2 * nbo * (size_t)ncq + 64), &q));
+    double* blkT = static_cast<double*>(q); double* farG = blkT + nblocks * nbo * nbo; double* farTmp = farG + nbo * nbo;
+    double* farX = farTmp + nbo * nbo / 2 + 16; double* farW = farX + nbo * (size_t)ncq;
+    int pnl = 0;
+    int first_low = npanels;                                  // first panel of the one-level part
+    for (int P0 = 0; P0 < npanels && M - P0 * NB > 2048; P0 += ppb) {
+      const int pend = P0 + ppb < npanels ? P0 + ppb : npanels;
+      const int bend = pend < npanels ? pend * NB : N;
+      bool ok = true;
+      for (pnl = P0; pnl < pend; pnl++) {
+        const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB;
+        if (nb < NB) { ok = false; break; }                   // (a ragged last panel: only when L is not a multiple of 16; handled below)
+        ND4_TRY(hr.panel(j0, bend, false, pnl == pend - 1));
+      }
+      if (!ok) break;
+      ND4_TRY(hr.finish(bend, false, false));                 // the block's last reflector has no column of the block left to reach
+      first_low = pend;
+      if (bend < N) {
+        const int J = P0 * NB, nblk = (pend - P0) * NB, mJ = M - J, far = N - bend;
+        for (int mt = 0; mt < batch; mt++) {
+          const double* Vb = ws.V + (long)mt * ws.sV + (long)J * ws.ldv + J;
+          double* C = W + (long)mt * sW + (long)J * ld + bend;
+          double* Tb = blkT + (size_t)(P0 / ppb) * nbo * nbo;
+          ND4_TRY(wy_build_T(h, mJ, nblk, Vb, ws.ldv, ws.T + (long)mt * ws.sT + (long)P0 * NB * NB, NB, Tb, farG, farTmp));
+          ND4_TRY(nd4_gemm(h, true, false, nblk, far, mJ, 1.0, Vb, ws.ldv, 0, C, ld, 0, 0.0, farX, far, 0, 1));
+          ND4_TRY(nd4_gemm(h, true, false, nblk, far, nblk, 1.0, Tb, nblk, 0, farX, far, 0, 0.0, farW, far, 0, 1));
+          ND4_TRY(nd4_gemm(h, false, false, mJ, far, nblk, -1.0, Vb, ws.ldv, 0, farW, far, 0, 1.0, C, ld, 0, 1));
+        }
+      }
+    }
+    // the rest as one level: multi-workgroup panels with all remaining columns as side work, then the short tail panels
+    pnl = first_low;
+    for (; pnl < npanels; pnl++) {
+      const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
+      if (nb < NB || m < hr_min_rows) break;
+      ND4_TRY(hr.panel(j0, N, false, false));
+    }
+    ND4_TRY(hr.finish(N, false, true));
+    {
+      int pj0 = -1;
+      for (; pnl < npanels; pnl++) {
+        const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
+        const int wide0 = pj0 + 2 * NB, nwide = (pj0 >= 0 && wide0 < N) ? (N - wide0 + NB - 1) / NB : 0;
+        const int wc0 = j0 + nb;
+        const dim3 grid((unsigned)(1 + nwide), (unsigned)batch);
+        if (m <= 512)       hipLaunchKernelGGL(qr_panel_row_la<1>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, (double*)nullptr, 0l);
+        else if (m <= 1024) hipLaunchKernelGGL(qr_panel_row_la<2>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, (double*)nullptr, 0l);
+        else                hipLaunchKernelGGL(qr_panel_row_la<4>, grid, dim3(512), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb, pj0 < 0 ? 0 : pj0, wide0, nwide, (double*)nullptr, 0l);
+        if (wc0 < N) {
+          const dim3 gn((unsigned)((m + 255) / 256), (unsigned)batch);
+          hipLaunchKernelGGL(qr_narrow_x, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, j0, wc0, ws.Wp, ws.sWb);
+          hipLaunchKernelGGL(qr_narrow_apply, gn, dim3(256), 0, h->stream, W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0, ws.Wp, ws.sWb, 0);
+        }
+        pj0 = j0;
+      }
+      if (pj0 >= 0) {
+        const int j0 = (npanels - 1) * NB, nb = L - j0 < NB ? L - j0 : NB, wc0 = j0 + nb + NB;
+        if (wc0 < N)
+          hipLaunchKernelGGL(qr_update_blocks<512>, dim3((unsigned)((N - wc0 + NB - 1) / NB), (unsigned)batch), dim3(512), 0, h->stream,
+                             W, M, N, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, j0, wc0);
+      }
+      ND4_HIP(hipGetLastError());
+    }
+    ND4_TRY(hr.dump_stamps());
+    // ---- Q = H_0 H_1 ... [I; 0] by the block reflectors of 128 columns, applied backwards to E (the blocks of the one-level part
+    // get their T now) ----
+    {
+      const long sQ = (long)M * Lq;
+      ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, batch, sQ));
+      const int ncolsV = npanels * NB;
+      for (int mt = 0; mt < batch; mt++) {
+        for (int b = (int)nblocks - 1; b >= 0; b--) {
+          const int J = b * (int)nbo, nblk = ncolsV - J < (int)nbo ? ncolsV - J : (int)nbo, mJ = M - J, nq2 = Lq - J;
+          if (nq2 <= 0) continue;
+          const double* Vb = ws.V + (long)mt * ws.sV + (long)J * ws.ldv + J;
+          double* Tb = blkT + (size_t)b * nbo * nbo;
+          if (b * ppb >= first_low || batch > 1)               // (blocks of the tall part of a single matrix still hold their T)
+            ND4_TRY(wy_build_T(h, mJ, nblk, Vb, ws.ldv, ws.T + (long)mt * ws.sT + (long)b * ppb * NB * NB, NB, Tb, farG, farTmp));
+          double* Qs = Q + (long)mt * sQ + (long)J * Lq + J;
+          ND4_TRY(nd4_gemm(h, true, false, nblk, nq2, mJ, 1.0, Vb, ws.ldv, 0, Qs, Lq, 0, 0.0, farX, nq2, 0, 1));
+          ND4_TRY(nd4_gemm(h, false, false, nblk, nq2, nblk, 1.0, Tb, nblk, 0, farX, nq2, 0, 0.0, farW, nq2, 0, 1));
+          ND4_TRY(nd4_gemm(h, false, false, mJ, nq2, nblk, -1.0, Vb, ws.ldv, 0, farW, nq2, 0, 1.0, Qs, Lq, 0, 1));
+        }
+      }
+    }
+  } else {
+  // Two-level blocking for M > 2048 (round 3): every panel used to read-modify-write the whole trailing matrix with a K = 16 update
+  // (qr_vtc / qr_tw / rank-16 product). Now the panels of an outer block of 128 columns (ND4HIP_QR_OUTER) apply their reflectors to
+  // the block's own columns only; then the block's compact-WY factor T (128 x 128: the panels' factors on the diagonal,
+  // T12 = -T1 (V1^T V2) T2 level by level from ONE Gram matrix, the routine Q is formed with) takes all 128 reflectors to the rest at
+  // once on the tiled MFMA kernel: X = V^T C, W = T^T X, C -= V W (K = 128). M <= 2048 without look-ahead: one level.
+  static const int nbo_env = [] { const char* e = getenv("ND4HIP_QR_OUTER"); return e ? atoi(e) : 128; }();
+  const int ppb = (M > 2048 && nbo_env >= 32) ? nbo_env / NB : npanels;        // panels per outer block
+  double *farT = nullptr, *farG = nullptr, *farTmp = nullptr, *farX = nullptr, *farW = nullptr;
+  if (ppb < npanels) {
+    const size_t nbo = (size_t)ppb * NB;
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (nbo * nbo * 2 + nbo * nbo / 2 + 16 + 2 * nbo * (size_t)N + 64), &q));
+    farT = static_cast<double*>(q); farG = farT + nbo * nbo; farTmp = farG + nbo * nbo; farX = farTmp + nbo * nbo / 2 + 16; farW = farX + nbo * (size_t)N;
+  }
+  for (int P0 = 0; P0 < npanels; P0 += ppb) {
+  const int pend = P0 + ppb < npanels ? P0 + ppb : npanels;
+  const int bend = pend < npanels ? pend * NB : N;                                // the block's reflectors reach the columns up to here at once
+  for (int pnl = P0; pnl < pend; pnl++) {
     const int j0 = pnl * NB, nb = L - j0 < NB ? L - j0 : NB, m = M - j0;
     if (m > 2048 && m <= 8192) {
       // the 16-column slot in parts on 1024 threads: two 8-column halves (m <= 4096: 4 rows x 8 columns per lane) or four
@@ -1845,8 +2030,21 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     else if (m <= 2048) launch_panel_row<4>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     ND4_HIP(hipGetLastError());
-    // trailing columns: C <- H^T C = (I - V T^T V^T) C
-    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + nb, ld, sW, N - j0 - nb));
+    // trailing columns of the outer block: C <- H^T C = (I - V T^T V^T) C
+    ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + nb, ld, sW, bend - j0 - nb));
+  }
+  if (bend < N) {                                                                  // the block's 128 reflectors on everything right of it
+    const int J = P0 * NB, nblk = (pend - P0) * NB, mJ = M - J, far = N - bend;
+    for (int mt = 0; mt < batch; mt++) {
+      const double* Vb = ws.V + (long)mt * ws.sV + (long)J * ws.ldv + J;
+      double* C = W + (long)mt * sW + (long)J * ld + bend;
+      ND4_TRY(wy_build_T(h, mJ, nblk, Vb, ws.ldv, ws.T + (long)mt * ws.sT + (long)P0 * NB * NB, NB, farT, farG, farTmp));
+      ND4_TRY(nd4_gemm(h, true, false, nblk, far, mJ, 1.0, Vb, ws.ldv, 0, C, ld, 0, 0.0, farX, far, 0, 1));
+      ND4_TRY(nd4_gemm(h, true, false, nblk, far, nblk, 1.0, farT, nblk, 0, farX, far, 0, 0.0, farW, far, 0, 1));
+      ND4_TRY(nd4_gemm(h, false, false, mJ, far, nblk, -1.0, Vb, ws.ldv, 0, farW, far, 0, 1.0, C, ld, 0, 1));
+    }
+  }
+  }
   }
 
   // ---- R out (tall: top N x N of the work matrix; else already in place, lower part zeroed by the panels) ----
@@ -1861,7 +2059,9 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   }
   // ---- Q = H_0 H_1 ... H_{p-1} [I; 0]: block reflectors applied backwards ----
   const long sQ = (long)M * Lq;
-  if (use_qt) {
+  if (hr_tall) {
+    // formed above from the block reflectors
+  } else if (use_qt) {
     ND4_TRY(nd4_transpose(h, Lq, M, QT, M, Q, Lq, batch, sQT, sQ));        // Q = (first Lq rows of Q^T)^T
   } else if (!wy_off && batch <= 4 && L >= 256) {
     ND4_TRY(form_q_compact_wy(h, ws, batch, M, Lq, npanels, Q, sQ));
@@ -1934,15 +2134,11 @@ int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool 
 // groups, applied level by level (groups of bs, 2 bs, 4 bs, ... columns). One Gram matrix V^T V (TN GEMM), two
 // strided-batched small GEMMs per level, W = T V[0:Lq,:]^T and Q = E - V W: ~20-30 launches and 6 M n^2 flop on the MFMA
 // kernels instead of a backward loop of rank-bs updates. n must be a multiple of bs; zero columns of V are harmless.
-int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* Tdiag, int bs, double* Q, int Lq) {
-  Nd4WsScope scope(h);
-  void* p = nullptr;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)n * n * 2 + (size_t)n * n / 2 + (size_t)n * Lq + 64), &p));
-  double* G = static_cast<double*>(p);
-  double* Tall = G + (size_t)n * n;
-  double* tmp = Tall + (size_t)n * n;
-  double* W = tmp + (size_t)n * n / 2 + 16;
-  ND4_TRY(nd4_gemm(h, true, false, n, n, M, 1.0, V, n, 0, V, n, 0, 0.0, G, n, 0, 1));
+// The n x n compact-WY factor T of n reflector columns V [M, n] (leading dimension ldv) from its bs x bs diagonal blocks Tdiag
+// ([n / bs][bs][bs]; bs = 1: the taus) and the Gram matrix V^T V: T[1,2] = -T1 (V1^T V2) T2 for two adjacent groups, level by level
+// (groups of bs, 2 bs, 4 bs, ... columns). G, tmp: workspaces of n * n and n * n / 2 + 16 doubles. n must be a multiple of bs.
+static int wy_build_T(nd4hip_handle* h, int M, int n, const double* V, long ldv, const double* Tdiag, int bs, double* Tall, double* G, double* tmp) {
+  ND4_TRY(nd4_gemm(h, true, false, n, n, M, 1.0, V, ldv, 0, V, ldv, 0, 0.0, G, n, 0, 1));
   ND4_HIP(hipMemsetAsync(Tall, 0, sizeof(double) * (size_t)n * n, h->stream));
   hipLaunchKernelGGL(wy_t_diag, dim3((unsigned)(n / bs)), dim3((unsigned)(bs * bs)), 0, h->stream, Tdiag, Tall, n, bs);
   ND4_HIP(hipGetLastError());
@@ -1961,6 +2157,18 @@ int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* T
       ND4_TRY(nd4_gemm(h, false, false, b, n2, b, -1.0, Tall + (long)i0 * (n + 1), n, 0, tmp, n2, 0, 0.0, Tall + (long)i0 * n + i0 + b, n, 0, 1));
     }
   }
+  return 0;
+}
+
+int nd4_wy_form(nd4hip_handle* h, int M, int n, const double* V, const double* Tdiag, int bs, double* Q, int Lq) {
+  Nd4WsScope scope(h);
+  void* p = nullptr;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * ((size_t)n * n * 2 + (size_t)n * n / 2 + (size_t)n * Lq + 64), &p));
+  double* G = static_cast<double*>(p);
+  double* Tall = G + (size_t)n * n;
+  double* tmp = Tall + (size_t)n * n;
+  double* W = tmp + (size_t)n * n / 2 + 16;
+  ND4_TRY(wy_build_T(h, M, n, V, n, Tdiag, bs, Tall, G, tmp));
   ND4_TRY(nd4_gemm(h, false, true, n, Lq, n, 1.0, Tall, n, 0, V, n, 0, 0.0, W, Lq, 0, 1));                   // W = T V[0:Lq,:]^T
   ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, 1, (long)M * Lq));
   return nd4_gemm(h, false, false, M, Lq, n, -1.0, V, n, 0, W, Lq, 0, 1.0, Q, Lq, 0, 1);                     // Q = E - V W

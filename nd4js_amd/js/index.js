@@ -18,7 +18,7 @@ const path = require('path');
 let addon = null;
 function native() {
   if (addon === null) {
-    try { addon = require(path.join(__dirname, 'nd4hip_napi.node')); }
+    try { addon = require(process.env.ND4HIP_NAPI_ADDON || path.join(__dirname, 'nd4hip_napi.node')); }   // (override: the sanitizer build of the shim, tools/check_sanitize.sh)
     catch (e) { throw new Error('nd4hip: cannot load the N-API addon (' + e.message + '). Build it with `python -m nd4js_amd.build`; there is no CPU fallback.'); }
   }
   return addon;
@@ -214,6 +214,9 @@ function makeLa(NDA, fallback) {
                         return new DeviceNDArray(Int32Array.from(a.shape), DevBuf.from(a.data)); };
   la.to_host = a => isDev(a) ? a.toHost(NDA) : asarray(a);
   la.synchronize = () => native().synchronize();
+  // per-call profile of the C ABI (nd4hip_profile_enable / nd4hip_profile_last): kernel ms, algorithmic flops and bytes per device
+  la.profile_enable = on => native().profile_enable(on !== false);
+  la.profile_last = () => native().profile_last();
 
   la.matmul2 = function matmul2(a, b) {
     a = asarray(a); b = asarray(b);
@@ -554,9 +557,25 @@ function makeLa(NDA, fallback) {
 
 const standalone = makeLa(NDArray, null);
 
-/** Patch a loaded nd4js instance in place: the hot-path functions run on the GPU. Returns nd. */
-function install(nd) {
+// estimated work of a call (flops, SURVEY.md 8d conventions up to a constant): what install(nd, {minWork}) compares with
+function estimatedWork(name, args) {
+  const dims = a => { const s = a && a.shape ? Array.from(a.shape) : null; if (!s || s.length < 2) return null;
+                      let b = 1; for (let i = 0; i < s.length - 2; i++) b *= s[i]; return [b, s[s.length - 2], s[s.length - 1]]; };
+  const a = dims(args[0]);
+  if (!a) return Infinity;                                  // nested JS arrays etc.: let the accelerated path coerce them
+  if (name === 'matmul2') { const b = dims(args[1]); return b ? 2 * Math.max(a[0], b[0]) * a[1] * a[2] * b[2] : Infinity; }
+  if (name === 'matmul') { let w = 0; for (let i = 0; i + 1 < args.length; i++) { const x = dims(args[i]), y = dims(args[i + 1]); if (!x || !y) return Infinity; w += 2 * Math.max(x[0], y[0]) * x[1] * x[2] * y[2]; } return w; }
+  return a[0] * a[1] * a[2] * Math.min(a[1], a[2]);
+}
+
+/** Patch a loaded nd4js instance in place: the hot-path functions run on the GPU. Returns nd.
+ *  opts.minWork (default 0 = off): a call whose estimated work (flops: 2 I K J for products, M N min(M, N) per matrix for
+ *  decompositions and solves) is below it — and whose operands all live on the host — is forwarded to the HOST MODULE'S OWN
+ *  function (`nd.la.*` as it was before install; never to this repo's oracle): one tiny matrix costs 50 us - 1 ms through any GPU
+ *  path (the reference's own suites live at N <= 161: _generic_test_svd_decomp.js:308-336, lu_test.js:82-94). */
+function install(nd, opts) {
   if (!nd || !nd.la || !nd.NDArray) throw new Error('nd4hip.install(nd): pass the nd4js module.');
+  const minWork = opts && opts.minWork > 0 ? +opts.minWork : 0;
   const original = {matmul2: nd.la.matmul2, matmul: nd.la.matmul, qr_decomp: nd.la.qr_decomp, qr_decomp_full: nd.la.qr_decomp_full,
                     lu_decomp: nd.la.lu_decomp, svd_decomp: nd.la.svd_decomp, svd_dc: nd.la.svd_dc,
                     lu_solve: nd.la.lu_solve, tril_solve: nd.la.tril_solve, triu_solve: nd.la.triu_solve,
@@ -566,8 +585,17 @@ function install(nd) {
   const acc = makeLa(nd.NDArray, original);
   const target = Object.isFrozen(nd.la) || !Object.getOwnPropertyDescriptor(nd.la, 'matmul2').writable ? null : nd.la;
   const patched = target || Object.create(nd.la);
-  for (const k of Object.keys(original)) Object.defineProperty(patched, k, {value: acc[k], writable: true, enumerable: true, configurable: true});
-  for (const k of ['to_device', 'to_host', 'synchronize', 'DeviceNDArray'])          // §8f N3 extension, not in the reference
+  const route = k => {
+    if (!minWork || typeof original[k] !== 'function') return acc[k];
+    const f = function (...args) {
+      const onHost = args.every(x => !(x instanceof acc.DeviceNDArray));
+      return onHost && estimatedWork(k, args) < minWork ? original[k].apply(nd.la, args) : acc[k](...args);
+    };
+    Object.defineProperty(f, 'name', {value: k});
+    return f;
+  };
+  for (const k of Object.keys(original)) Object.defineProperty(patched, k, {value: route(k), writable: true, enumerable: true, configurable: true});
+  for (const k of ['to_device', 'to_host', 'synchronize', 'DeviceNDArray', 'profile_enable', 'profile_last'])   // §8f N3 / §8b extensions, not in the reference
     Object.defineProperty(patched, k, {value: acc[k], writable: true, enumerable: false, configurable: true});
   if (!target) { try { nd.la = patched; } catch (e) { /* exported getter: caller uses the returned object */ } }
   patched.__nd4hip_original__ = original;

@@ -442,7 +442,9 @@ def cholesky_decomp(S, device=None):
         _lib.check(h.lib.nd4hip_dpotrf_batched(h.ptr, int(np.prod(S.shape[:-2], dtype=np.int64)), N, _ptr(S), _ptr(L)))
     except _lib.Nd4HipError as e:
         if e.code == -5:
-            raise ValueError("Matrix contains NaNs or is (near) singular.")      # cholesky.js:43-44
+            # cholesky.js:43-44; a multi-device handle adds which of its devices reported it
+            where = str(e)[str(e).find(" (device "):] if " (device " in str(e) else ""
+            raise ValueError("Matrix contains NaNs or is (near) singular." + where)
         raise
     return L
 

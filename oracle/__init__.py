@@ -29,8 +29,11 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        so = os.environ.get("ND4_ORACLE_SO")            # e.g. the sanitizer build (make -C oracle asan; tools/check_sanitize.sh)
+        if not so:
+            build()
+            so = _SO
+        L = ctypes.CDLL(so)
         L.nd4o_uniform.restype = ctypes.c_double
         L.nd4o_uniform.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.nd4o_fill_uniform.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _i64, _dp]

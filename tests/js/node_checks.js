@@ -92,12 +92,36 @@ if (mode === 'install') {
   }
   { const svs = new nd.NDArray(Int32Array.of(2, 3), Float64Array.of(4, 2, 1e-12, 3, 3, 3));       // same ranks as the reference's svd_rank
     assert.deepStrictEqual(Array.from(nd2.la.svd_rank(svs).data), Array.from(nd2.la.__nd4hip_original__.svd_rank(svs).data)); }
+  { // install(nd, {minWork}): tiny float64 calls go to the HOST MODULE's own functions (bit-identical to them, no GPU needed)
+    delete require.cache[require.resolve(process.argv[3])];
+    const ndB = require(process.argv[3]), ndC = la.install(ndB, {minWork: 1e5}), orig = ndC.la.__nd4hip_original__;
+    const f64 = (seed, shape) => new ndB.NDArray(Int32Array.from(shape), Float64Array.from(fill(seed, shape).data));
+    const x = f64(5, [3, 8, 8]);                                       // 3 * 8 * 8 * 8 = 1536 < minWork
+    const [LU, P] = ndC.la.lu_decomp(x), [LU0, P0] = orig.lu_decomp(x);
+    assert.deepStrictEqual(Array.from(LU.data), Array.from(LU0.data)); assert.deepStrictEqual(Array.from(P.data), Array.from(P0.data));
+    const [U, sv, V] = ndC.la.svd_decomp(x), [U0, sv0, V0] = orig.svd_decomp(x);
+    assert.deepStrictEqual(Array.from(sv.data), Array.from(sv0.data)); assert.deepStrictEqual(Array.from(U.data), Array.from(U0.data));
+    assert.deepStrictEqual(Array.from(ndC.la.matmul2(x, x).data), Array.from(orig.matmul2(x, x).data));
+    if (la.device_count() === 0)                                       // 64^3 = 262144 >= minWork: the accelerated path, which fails loudly here
+      assert.throws(() => ndC.la.lu_decomp(f64(6, [64, 64])), /no HIP device/);
+  }
   console.log('node install checks ok');
 }
 
 if (mode === 'gpu') {
   const dir = process.argv[3], man = JSON.parse(fs.readFileSync(path.join(dir, 'manifest.json'))).cases;
   const npy = (c, k) => loadNpy(path.join(dir, man[c].files[k]));
+  { // nd4hip_profile_enable / nd4hip_profile_last through the N-API table
+    la.profile_enable(true);
+    la.matmul2(fill(1, [64, 64]), fill(2, [64, 64]));
+    const pr = la.profile_last();
+    assert.ok(pr.length >= 1 && pr[0].valid && pr[0].op === 'dgemm_batched' && pr[0].flops === 2 * 64 * 64 * 64 && pr[0].bytes === 8 * 3 * 64 * 64 && pr[0].kernel_ms > 0);
+    la.lu_decomp(fill(3, [4, 96, 96]));
+    const pl = la.profile_last();
+    assert.ok(pl[0].op === 'dgetrf_batched' && Math.abs(pl[0].flops - 4 * 2 / 3 * 96 ** 3) < 1 && pl[0].kernel_ms > 0);
+    la.profile_enable(false);
+    assert.ok(!la.profile_last()[0].valid);
+  }
   { const m = man.c1_matmul64, C = la.matmul2(fill(m.seedA, m.shapeA), fill(m.seedB, m.shapeB));
     assert.ok(relerr(C.data, npy('c1_matmul64', 'C').data) <= 1e-13); }
   { const m = man.bc_matmul_a, C = la.matmul2(fill(m.seedA, m.shapeA), fill(m.seedB, m.shapeB));

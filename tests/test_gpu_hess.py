@@ -103,3 +103,16 @@ def test_blocked_path_skipped_steps(la):
     lo = N - 48
     assert np.abs(h[lo:] - ho[lo:]).max() <= 1e-11 * np.abs(mixed).max()
     assert np.abs(u[:, lo:] - uo[:, lo:]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_blocked_path_large(la, N):
+    """the blocked path at the benchmark size (2048^2: properties of hessenberg_test.js) and against the oracle at 1024^2
+    (the largest tested size used to be 600)."""
+    a = rng.matrix(6600 + N, N, N)
+    u, h = la.hessenberg_decomp(a)
+    check_props(a, u, h)
+    if N <= 1024:
+        uo, ho = oracle.hessenberg_decomp(a)
+        assert np.abs(h - ho).max() <= 64 * EPS * N * np.abs(a).max() * N ** 0.5
+        assert np.abs(u - uo).max() <= 64 * EPS * N

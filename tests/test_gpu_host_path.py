@@ -80,3 +80,42 @@ def test_multi_device_handle():
         assert np.array_equal(lu, lu1) and np.array_equal(p, p1)
         hn.close()
     h1.close()
+
+
+def test_multi_device_code_runs_on_one_gpu(monkeypatch):
+    """ND4HIP_TEST_ALLOW_DUP_DEVICES=1 lets nd4hip_create_multi take [0, 0, 0], so that the per-device host threads, the
+    block partition (uneven: 13 = 5 + 4 + 4), the merged SVD audit (max sweeps / off-norm, rotation sum) and the first error with its
+    device execute on the one-GPU box: results bit-identical to n_dev = 1 (units: svd_dc.js:918-925, lu.js:34-40), and a block that
+    fails reports the device it ran on and leaves the handle usable."""
+    monkeypatch.setenv("ND4HIP_TEST_ALLOW_DUP_DEVICES", "1")
+    h3 = _lib.Handle([0, 0, 0])
+    assert h3.devices() == [0, 0, 0]
+    a = rng.matrix(6130, 13, 96, 96)
+    info1, info3 = {}, {}
+    ref = la.svd_decomp(a, info=info1)
+    got = la.svd_decomp(a, device=h3, info=info3)
+    assert all(np.array_equal(x, y) for x, y in zip(got, ref))
+    assert info3["sweeps"] == info1["sweeps"] and info3["rotations"] == info1["rotations"] and info3["offnorm"] == info1["offnorm"]
+    lu, p = la.lu_decomp(a, device=h3)
+    lu1, p1 = la.lu_decomp(a)
+    assert np.array_equal(lu, lu1) and np.array_equal(p, p1)
+    q, r = la.qr_decomp(a, device=h3)
+    q1, r1 = la.qr_decomp(a)                               # (blocks of <= 8 matrices take the multi-workgroup panels, the batch of 13
+    assert relerr(q, q1) <= 1e-13 and relerr(r, r1) <= 1e-13   #  the thread-per-row ones: rounding-level differences, as between chunks)
+    # fewer members than devices: the spare devices get nothing
+    got2 = la.svd_decomp(a[:2], device=h3)
+    assert all(np.array_equal(x, y[:2]) for x, y in zip(got2, ref))
+    # a failing block: member 9 lies in the third block (device index 2 of the handle)
+    x = rng.matrix(6131, 13, 128, 32)
+    s = x @ np.swapaxes(x, -1, -2) + 128 * np.eye(128)
+    bad = s.copy()
+    bad[9, 50, 50] = -1.0
+    for _ in range(2):
+        with pytest.raises(ValueError, match="device 2 of the handle"):
+            la.cholesky_decomp(bad, device=h3)
+        L = la.cholesky_decomp(s, device=h3)               # the handle and all three blocks' staging stay usable
+        assert np.array_equal(L, la.cholesky_decomp(s))
+    h3.close()
+    monkeypatch.delenv("ND4HIP_TEST_ALLOW_DUP_DEVICES")
+    with pytest.raises(_lib.Nd4HipError):
+        _lib.Handle([0, 0])

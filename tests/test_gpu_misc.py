@@ -102,3 +102,39 @@ def test_batches_longer_than_the_grid_limit():
     last = slice(b - 3, b)
     uo, so, vo = la.svd_decomp(a[last])
     assert np.allclose(sv[last], so, rtol=0, atol=1e-13)           # the tail chunk is really computed, not left behind
+
+
+def test_profile_last(la, monkeypatch):
+    """nd4hip_profile_enable / nd4hip_profile_last: kernel time and the algorithmic work of the last call, per device of
+    the handle; off by default; the inner calls of a composite operation (QR inside the rectangular SVD) do not overwrite the record."""
+    import torch
+    from nd4js_amd import _lib, dev
+    h = _lib.handle(0)
+    assert not h.profile_last()[0]["valid"]
+    h.profile_enable(True)
+    try:
+        A = dev.fill_uniform(41, (512, 512))
+        dev.matmul2(A, A)
+        p = h.profile_last()
+        assert len(p) == 1 and p[0]["valid"] and p[0]["op"] == "dgemm_batched" and p[0]["device"] == 0
+        assert p[0]["flops"] == 2.0 * 512 ** 3 and p[0]["bytes"] == 8.0 * 3 * 512 * 512 and 0.0 < p[0]["kernel_ms"] < 50.0
+        dev.lu_decomp(A)
+        p = h.profile_last()
+        assert p[0]["op"] == "dgetrf_batched" and abs(p[0]["flops"] - 2.0 / 3.0 * 512 ** 3) < 1.0 and p[0]["kernel_ms"] > 0.0
+        T = dev.fill_uniform(42, (700, 200))
+        dev.svd_decomp(T)                                   # QR pre-reduction + GEMMs inside: still one record, of the SVD
+        p = h.profile_last()
+        assert p[0]["op"] == "dgesvdj_batched" and p[0]["flops"] == 4.0 * 700 ** 2 * 200 + 8.0 * 700 * 200 ** 2 + 9.0 * 200 ** 3
+    finally:
+        h.profile_enable(False)
+    assert not h.profile_last()[0]["valid"]
+    # a multi-device handle reports one record per device (the same GPU three times on a one-GPU box)
+    monkeypatch.setenv("ND4HIP_TEST_ALLOW_DUP_DEVICES", "1")
+    h3 = _lib.Handle([0, 0, 0])
+    h3.profile_enable(True)
+    a = rng.matrix(2100, 6, 64, 64)
+    la.lu_decomp(a, device=h3)
+    p3 = h3.profile_last()
+    assert len(p3) == 3 and all(r["valid"] and r["op"] == "dgetrf_batched" and abs(r["flops"] - 2 * 2.0 / 3.0 * 64 ** 3) < 1.0 for r in p3)
+    h3.close()
+    torch.cuda.synchronize()
