@@ -112,6 +112,16 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
             torch.cuda.synchronize()
         out["lu%d" % N] = _entry(_median_ms(lambda: dev.lu_decomp(A), h), 2.0 / 3.0 * N ** 3)
         out["qr%d" % N] = _entry(_median_ms(lambda: dev.qr_decomp(A), h), 8.0 / 3.0 * N ** 3)
+        # beyond the register-resident panels (N > 2048: two-level blocking; the reference author's own benchmark range ends at
+        # N ~ 3100, benchmarks/bench_la_decomps.html:285-288): same flop conventions, median of 5
+        if os.environ.get("ND4_BENCH_LARGE", "1") != "0":
+            for NL in (4096, 8192):
+                AL = dev.fill_uniform(17, (NL, NL))
+                out["lu%d" % NL] = _entry(_median_ms(lambda: dev.lu_decomp(AL), h, reps=5, warm=1), 2.0 / 3.0 * NL ** 3)
+                out["qr%d" % NL] = _entry(_median_ms(lambda: dev.qr_decomp(AL), h, reps=5, warm=1), 8.0 / 3.0 * NL ** 3)
+                out["lu%d" % NL]["timing"] = out["qr%d" % NL]["timing"] = "median of 5 (HIP events)"
+                del AL
+                torch.cuda.empty_cache()
         # N1: lu_solve with N right-hand sides on the device-resident factors: 2 N^2 J flop
         LUd, Pd = dev.lu_decomp(A)
         Y = dev.fill_uniform(11, (N, N))

@@ -16,9 +16,13 @@ ks svd_batch256x512 python3 $R/tools/prof_batch.py 256
 ks hess2048 python3 $R/tools/prof_hess.py 2048 hess
 ks bidiag2048 python3 $R/tools/prof_hess.py 2048 bidiag
 ks lu_solve2048 python3 $R/tools/prof_ops.py lusolve
+ks qr4096 python3 $R/tools/prof_ops.py qr --n 4096 --reps 2
+ks lu_qr_8192 python3 $R/tools/prof_ops.py lu qr --n 8192 --reps 1
 pmc gemm_fetch FETCH_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_write WRITE_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
+pmc lu8192_fetch FETCH_SIZE python3 $R/tools/prof_ops.py lu --n 8192 --reps 1
+pmc lu8192_write WRITE_SIZE python3 $R/tools/prof_ops.py lu --n 8192 --reps 1
 pmc svd_fetch FETCH_SIZE python3 $R/tools/prof_ops.py svd --reps 1
 pmc svd_write WRITE_SIZE python3 $R/tools/prof_ops.py svd --reps 1
 ls $out
