@@ -661,7 +661,8 @@ struct QrhP {
   int nxp;                          // partials of X to sum in phase A
   int nrow;                         // row workgroups of this launch
   int ngp;                          // Gram partials to sum (phase B: phase A's row workgroups; phase C: phase B's)
-  int wide0, nnw, nrc;              // side work (reflector pj0): nnw column blocks of W from wide0 on (then blocks of Q^T), nrc row chunks each
+  int wide0, nnw, nqb, nrc;         // side work (reflector pj0): nnw column blocks of W from wide0 on, then nqb blocks of Q^T; nrc row chunks each;
+                                    // a side workgroup takes TWO adjacent blocks (pairs of W blocks first, then pairs of Q^T blocks)
   int nseg; QrhSeg seg[2];          // the side work of this launch: workgroups nrow.. walk these segments
   int skip_x;                       // phase C: no partial X for the next panel (last panel of an outer block: the block update covers it)
   long long* stamps; int stamp_slot; // debug (ND4HIP_QR_STAMPS): 100 MHz wall-clock stamps of workgroup 0, 8 per launch
@@ -782,22 +783,27 @@ __device__ __forceinline__ void qrh_reduce_store(double* __restrict__ s_part, co
   }
 }
 
-// The wave's 64 rows [rb, rb + 64) of a 16-column block: C <- C - V (T^T X), X = the sum of nx partials (256 doubles apart, fixed
-// order, the same in every workgroup). Vcol / Ccol point at (row 0, first column) of the reflector / the block. On return c holds
-// the updated tile in accumulator layout (c[q][r]: row rb + 16 q + fk + 4 r, column fx; rows outside [0, M) are zero).
-// s_w: 512 doubles of LDS. Every thread of the workgroup must call it.
-__device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const double* __restrict__ Xsrc, int nx, const double* __restrict__ Tg,
+// The wave's 64 rows [rb, rb + 64) of NBLK adjacent 16-column blocks: C <- C - V (T^T X), X (per block) = the sum of nx partials
+// (256 doubles apart, fixed order, the same in every workgroup; block b's partials start at Xsrc + b * xstride). Vcol / Ccol point at
+// (row 0, first column) of the reflector / the first block; nc = columns in all (<= 16 NBLK). On return c[b] holds the updated tile of
+// block b in accumulator layout (c[b][q][r]: row rb + 16 q + fk + 4 r, column 16 b + fx; rows outside [0, M) are zero).
+// s_w: 256 (NBLK + 1) doubles of LDS. Every thread of the workgroup must call it. The reflector rows are loaded ONCE for all blocks.
+template <int NBLK>
+__device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const double* __restrict__ Xsrc, long xstride, int nx, const double* __restrict__ Tg,
                                                const double* __restrict__ Vcol, long ldv, double* __restrict__ Ccol, long ldc, int nc,
-                                               int rb, int M, d4 (&c)[4]) {
+                                               int rb, int M, d4 (&c)[NBLK][4]) {
   const int t = threadIdx.x, lane = t & 63, fx = lane & 15, fk = lane >> 4;
-  const bool cok = fx < nc;
   double av[4][4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int rc = rb + q * 16 + fk + 4 * r;
-      c[q][r] = (rc >= 0 && rc < M && cok) ? Ccol[(long)rc * ldc + fx] : 0.0;
+    for (int b = 0; b < NBLK; b++) {
+      const bool cok = b * NB + fx < nc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        c[b][q][r] = (rc >= 0 && rc < M && cok) ? Ccol[(long)rc * ldc + b * NB + fx] : 0.0;
+      }
     }
     const int ra = rb + q * 16 + fx;
     if (ra >= 0 && ra < M) {                                           // 32 contiguous bytes per lane: k-step kk <-> column 4 fk + kk
@@ -806,33 +812,38 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
       av[q][0] = v0.x; av[q][1] = v0.y; av[q][2] = v1.x; av[q][3] = v1.y;
     } else { av[q][0] = av[q][1] = av[q][2] = av[q][3] = 0.0; }
   }
-  double* s_X = s_w;
-  double* s_Tm = s_w + 256;
-  if (t < 256) {
-    s_X[t] = qrh_sum_parts(Xsrc + t, nx);
-    s_Tm[t] = Tg[t];
+  double* s_X = s_w;                                                   // NBLK x 256
+  double* s_Tm = s_w + NBLK * 256;
+  if (t < NBLK * 256) {
+    const int b = t >> 8, e = t & 255;
+    s_X[t] = (b * NB < nc) ? qrh_sum_parts(Xsrc + b * xstride + e, nx) : 0.0;
+    if (t < 256) s_Tm[t] = Tg[t];
   }
   __syncthreads();
   double wv = 0.0;
-  if (t < 256) {
-    const int i = t / 16, j = t % 16;
+  if (t < NBLK * 256) {
+    const int b = t >> 8, i = (t & 255) / 16, j = t % 16;
 #pragma unroll
-    for (int l = 0; l < NB; l++) wv += s_Tm[l * 16 + i] * s_X[l * 16 + j];                   // T^T X, T a full 16 x 16 matrix
+    for (int l = 0; l < NB; l++) wv += s_Tm[l * 16 + i] * s_X[b * 256 + l * 16 + j];        // T^T X, T a full 16 x 16 matrix
   }
   __syncthreads();
-  if (t < 256) s_X[t] = -wv;
+  if (t < NBLK * 256) s_X[t] = -wv;
   __syncthreads();
-  double bw[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; kk++) bw[kk] = s_X[(4 * fk + kk) * 16 + fx];
+  for (int b = 0; b < NBLK; b++) {
+    const bool cok = b * NB + fx < nc;
+    double bw[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+    for (int kk = 0; kk < 4; kk++) bw[kk] = s_X[b * 256 + (4 * fk + kk) * 16 + fx];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+    for (int q = 0; q < 4; q++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int rc = rb + q * 16 + fk + 4 * r;
-      if (rc >= 0 && rc < M && cok) Ccol[(long)rc * ldc + fx] = c[q][r];
+      for (int kk = 0; kk < 4; kk++) c[b][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[b][q], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        if (rc >= 0 && rc < M && cok) Ccol[(long)rc * ldc + b * NB + fx] = c[b][q][r];
+      }
     }
   }
 }
@@ -840,42 +851,60 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
 // ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks (trailing columns of W, then
 // Q^T), in two phases split over 512-row chunks like the panel itself: partial X = V^T C (SEG_NX, launch A), C -= V (T^T X)
 // (SEG_NA: the blocks of W in launch B, whose first one phase C reads; those of Q^T in launch C) ----
-struct QrhSide { double* C; long ldc; int c0, nc, cb, rc; };
+struct QrhSide { double* C; long ldc; int c0, nc, cb, rc; };   // cb: first block (index among W blocks, then Q^T blocks); nc: columns of the pair
 __device__ __forceinline__ QrhSide qrh_near_of(const QrhP& P, int mat, int e) {
   QrhSide s;
-  s.cb = e / P.nrc; s.rc = e % P.nrc;
-  if (s.cb < P.nnw) { s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB; s.nc = P.N - s.c0 < NB ? P.N - s.c0 : NB; }
-  else              { s.C = P.QT + mat * P.strideQT; s.ldc = P.M; s.c0 = (s.cb - P.nnw) * NB; s.nc = P.M - s.c0 < NB ? P.M - s.c0 : NB; }
+  const int pr = e / P.nrc, nwp = (P.nnw + 1) / 2;
+  s.rc = e % P.nrc;
+  if (pr < nwp) {
+    s.cb = 2 * pr; s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB;
+    const int end = P.wide0 + P.nnw * NB < P.N ? P.wide0 + P.nnw * NB : P.N;
+    s.nc = end - s.c0 < 2 * NB ? end - s.c0 : 2 * NB;
+  } else {
+    const int qb = 2 * (pr - nwp);
+    s.cb = P.nnw + qb; s.C = P.QT + mat * P.strideQT; s.ldc = P.M; s.c0 = qb * NB;
+    s.nc = P.M - s.c0 < 2 * NB ? P.M - s.c0 : 2 * NB;
+  }
   return s;
 }
-// partial X = V^T C over one 512-row chunk of one column block (the reflector at vj0)
+// partial X = V^T C over one 512-row chunk of a pair of column blocks (the reflector at vj0): the reflector slabs are loaded once
 __device__ __forceinline__ void qrh_side_x(const QrhP& P, int mat, const QrhSide& s, int vj0, double* __restrict__ dst, double* __restrict__ s_buf) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
   const int rb = vj0 + s.rc * 512 + wave * 64;
   const double* V = P.Vall + mat * P.strideV + vj0;
-  const bool cok = fx < s.nc;
-  double c[16], v[16];
+  const bool ok0 = fx < s.nc, ok1 = NB + fx < s.nc;
+  double c0[16], c1[16], v[16];
 #pragma unroll
-  for (int u = 0; u < 16; u++) {                                       // 16 slabs of 4 rows: both operands in the same (row fk, column fx) layout
+  for (int u = 0; u < 16; u++) {                                       // 16 slabs of 4 rows: all operands in the same (row fk, column fx) layout
     const int r = rb + 4 * u + fk;
-    c[u] = (r < P.M && cok) ? s.C[(long)r * s.ldc + s.c0 + fx] : 0.0;
-    v[u] = r < P.M ? V[(long)r * P.ldv + fx] : 0.0;
+    const bool rok = r < P.M;
+    const double* cp = s.C + (long)r * s.ldc + s.c0 + fx;
+    c0[u] = (rok && ok0) ? cp[0] : 0.0;
+    c1[u] = (rok && ok1) ? cp[NB] : 0.0;
+    v[u] = rok ? V[(long)r * P.ldv + fx] : 0.0;
   }
-  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
+  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0, y0 = x0, y1 = x0;
 #pragma unroll
   for (int u = 0; u < 16; u += 2) {
-    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c[u], x0, 0, 0, 0);
-    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c[u + 1], x1, 0, 0, 0);
+    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c0[u], x0, 0, 0, 0);
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c1[u], y0, 0, 0, 0);
+    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c0[u + 1], x1, 0, 0, 0);
+    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c1[u + 1], y1, 0, 0, 0);
   }
   qrh_reduce_store(s_buf, x0, x1, dst);
+  if (s.nc > NB) {                                                     // (uniform) the pair's second block: the next slot of Xs
+    __syncthreads();
+    qrh_reduce_store(s_buf, y0, y1, dst + (long)P.nrc * 256);
+  }
 }
-// C -= V (T^T X) on one 512-row chunk of one near column block
+// C -= V (T^T X) on one 512-row chunk of a pair of column blocks
 __device__ __forceinline__ void qrh_near_apply(const QrhP& P, int mat, int e, double* __restrict__ s_buf) {
   const QrhSide s = qrh_near_of(P, mat, e);
   const int wave = threadIdx.x >> 6;
-  d4 c[4];
-  qrh_apply_rows(s_buf, P.Xs + mat * P.strideXs + (long)s.cb * P.nrc * 256, P.nrc, P.Tall + mat * P.strideT + (long)(P.pj0 / NB) * NB * NB,
-                 P.Vall + mat * P.strideV + P.pj0, P.ldv, s.C + s.c0, s.ldc, s.nc, P.pj0 + s.rc * 512 + wave * 64, P.M, c);
+  d4 c[2][4];
+  qrh_apply_rows<2>(s_buf, P.Xs + mat * P.strideXs + (long)s.cb * P.nrc * 256, (long)P.nrc * 256, P.nrc,
+                    P.Tall + mat * P.strideT + (long)(P.pj0 / NB) * NB * NB,
+                    P.Vall + mat * P.strideV + P.pj0, P.ldv, s.C + s.c0, s.ldc, s.nc, P.pj0 + s.rc * 512 + wave * 64, P.M, c);
 }
 // workgroup i of a launch's side work
 __device__ __forceinline__ void qrh_side(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
@@ -909,11 +938,12 @@ __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
   double* A = P.Wm + mat * P.strideW;
   const int j0 = P.j0, ub = j0 - NB, M = P.M;
   const int rb = ub + (g * 8 + wave) * 64;
-  d4 c[4];
+  d4 cc[1][4];
+  d4 (&c)[4] = cc[0];
   qrh_stamp(P, 0);
   if (P.pj0 >= 0) {
-    qrh_apply_rows(s_buf, P.Xp + mat * P.strideXp, P.nxp, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
-                   P.Vall + mat * P.strideV + ub, P.ldv, A + j0, P.ld, NB, rb, M, c);
+    qrh_apply_rows<1>(s_buf, P.Xp + mat * P.strideXp, 0, P.nxp, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                      P.Vall + mat * P.strideV + ub, P.ldv, A + j0, P.ld, NB, rb, M, cc);
     __syncthreads();                                                  // s_buf is reused below
     qrh_stamp(P, 1);
   } else {
@@ -989,7 +1019,9 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
   __syncthreads();
   qrh_stamp(P, 1);
   if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);                                     // the chain wave shares its CU with riding side workgroups
     bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < 16; k++) ok = ok && (s_db[k] > 0.0);
     if (lane == 0) s_flag = ok ? 0 : 1;
@@ -1151,7 +1183,7 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   }
   __syncthreads();
   qrh_stamp(P, 3);
-  if (wave == 0) qrh_gj16(s_Z, s_K, s_S);
+  if (wave == 0) { __builtin_amdgcn_s_setprio(3); qrh_gj16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
   double bw[4];
 #pragma unroll
   for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
@@ -1643,7 +1675,8 @@ struct QrhHost {
     const int wide0 = pj + 2 * NB;
     P.wide0 = wide0; P.nrc = (P.M - pj + 511) / 512;
     P.nnw = wide0 < near_end ? (near_end - wide0 + NB - 1) / NB : 0;
-    nw_e = P.nnw * P.nrc; all_e = nw_e + (with_qt ? nq * P.nrc : 0);
+    P.nqb = with_qt ? nq : 0;
+    nw_e = ((P.nnw + 1) / 2) * P.nrc; all_e = nw_e + ((P.nqb + 1) / 2) * P.nrc;      // a workgroup takes two adjacent column blocks
   }
   int panel(int j0, int near_end, bool with_qt, bool skip_x) {
     const int m = P.M - j0;
@@ -1836,7 +1869,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
     P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
     P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
-    P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.skip_x = 0; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
+    P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 0; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
     static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
     P.stamps = nullptr; P.stamp_slot = 0;
     if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
