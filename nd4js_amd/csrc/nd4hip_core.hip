@@ -43,6 +43,9 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev_p0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_p1);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_aux_a, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_aux_b, hipEventDisableTiming);
   for (int i = 0; i < 2 && e == hipSuccess; i++) {
     e = hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming);
@@ -61,6 +64,9 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(h->device);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_aux_a) (void)hipEventDestroy(h->ev_aux_a);
+  if (h->ev_aux_b) (void)hipEventDestroy(h->ev_aux_b);
   for (int i = 0; i < 2; i++) { if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]); if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]); }
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   for (auto& b : h->ws) (void)hipFree(b.p);

@@ -23,6 +23,8 @@ struct nd4hip_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_order = nullptr;      // orders the workspace arena across a change of stream (nd4hip_set_stream)
   hipStream_t copy_stream = nullptr;  // H2D / D2H of the host-pointer entry points (overlaps the kernels on `stream`)
+  hipStream_t aux_stream = nullptr;   // second chain of the block-Jacobi sweeps (svd_block.hip), beside the first on `stream`
+  hipEvent_t ev_aux_a = nullptr, ev_aux_b = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_chunk[2] = {nullptr, nullptr};   // per staging set: inputs landed / kernels done
   std::vector<nd4hip_handle*> peers;  // further devices of a multi-device handle (nd4hip_create_multi); owned
   int num_cu = 256;

@@ -52,6 +52,26 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 __device__ __forceinline__ long pair_row(int x, int I, int J) { return x < BB ? (long)I * BB + x : (long)J * BB + (x - BB); }
 
+// Block pair (I < J) of slot `i` at step `s` of a sweep over n2 blocks. n2 > 0: the round-robin tournament of nd4_rr_pair.
+// n2 < 0 (n = -n2, n % 4 == 0): the block-recursive tournament of round 3, in which the slots [0, n/4) and [n/4, n/2) of every step
+// are two CLOSED groups for a whole phase (so that two chains of launches can run side by side, see nd4_jacobi_block_sweep):
+//   phase 1 (n/2 - 1 steps): round robin inside each half;  phase 2a (n/4 steps): H1a x H2a | H1b x H2b;  phase 2b (n/4 steps):
+//   H1a x H2b | H1b x H2a (cyclic shifts). Every pair once per sweep, n - 1 steps, as before.
+__host__ __device__ __forceinline__ void jacb_pair(int n2, int s, int i, int& I, int& J) {
+  if (n2 > 0) { nd4_rr_pair(n2, s, i, I, J); return; }
+  const int n = -n2, h = n / 2, q = n / 4;
+  const int grp = i >= q ? 1 : 0, ii = i - grp * q;
+  if (s < h - 1) {
+    nd4_rr_pair(h, s, ii, I, J);
+    I += grp * h; J += grp * h;
+  } else {
+    const int c = s - (h - 1), second = c >= q ? 1 : 0, cc = c - second * q;
+    I = grp * q + ii;
+    J = h + ((grp ^ second) ? q : 0) + (ii + cc) % q;
+  }
+}
+__host__ __device__ __forceinline__ int jacb_abs(int n2) { return n2 < 0 ? -n2 : n2; }
+
 // acc (16 tiles of the 64x64 Gram of the block pair) over the columns [col0, col0 + ncols) of W, for one wave.
 // The A and B fragments of a Gram product are the same register image; one 16-byte load feeds two MFMA k-steps.
 // The order in which the columns are summed is free (A and B fragment are the same registers), so lane (fx, fk) takes the
@@ -125,7 +145,7 @@ __global__ __launch_bounds__(256) void jacb_gram(const double* __restrict__ Wm, 
   const int pairIdx = blockIdx.x, chunk = blockIdx.y, mat = blockIdx.z;
   if (st[mat].done) return;
   int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  jacb_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const double* W = Wm + mat * sM;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -165,12 +185,12 @@ __device__ __forceinline__ void gram2_tiles(d4 (&acc)[3], const double (*st)[PB 
   }
 }
 __global__ __launch_bounds__(256) void jacb_gram2(const double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
-                                                   const JacState* __restrict__ st, double* __restrict__ Gpart, int nchunks, long sG_mat) {
+                                                   const JacState* __restrict__ st, double* __restrict__ Gpart, int nchunks, long sG_mat, int pair0) {
   __shared__ double s_x[2][PB][PB + 2];
-  const int pairIdx = blockIdx.x, chunk = blockIdx.y, mat = blockIdx.z;
+  const int pairIdx = blockIdx.x + pair0, chunk = blockIdx.y, mat = blockIdx.z;
   if (st[mat].done) return;
   int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  jacb_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const double* W = Wm + mat * sM;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen(const double* __restrict
   const int pairIdx = blockIdx.x, mat = blockIdx.y;
   if (st[mat].done) return;
   int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  jacb_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if constexpr (FUSED) {
@@ -406,7 +426,7 @@ __device__ __forceinline__ void eigen_p_body(double* __restrict__ stage_raw, con
   double (*QJ)[PB + 1] = stage;
   if (st[mat].done) return;
   int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  jacb_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < TB) {
@@ -586,7 +606,7 @@ __device__ __forceinline__ void apply_body(double* __restrict__ sq_raw, const in
   double (*sQ)[SQ_LD] = reinterpret_cast<double (*)[SQ_LD]>(sq_raw);
   if (st[mat].done || !flags[mat * sF_mat + pairIdx]) return;
   int I, J;
-  nd4_rr_pair(nblk2, step, pairIdx, I, J);
+  jacb_pair(nblk2, step, pairIdx, I, J);
   if (J >= nblk) return;
   double* X = (chunk < nchunks ? Wm : Utm) + mat * sM;
   if (chunk >= nchunks) chunk -= nchunks;
@@ -622,26 +642,26 @@ __device__ __forceinline__ void apply_body(double* __restrict__ sq_raw, const in
 __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                                      JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
                                                      double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
-                                                     unsigned long long* __restrict__ offmax, int precheck) {
+                                                     unsigned long long* __restrict__ offmax, int precheck, int pair0) {
   __shared__ double stage_raw[STAGE_DOUBLES];
-  eigen_p_body(stage_raw, blockIdx.x, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+  eigen_p_body(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
                offmax, precheck);
 }
 
 __global__ __launch_bounds__(256) void jacb_apply(double* __restrict__ Wm, double* __restrict__ Utm, int N, long sM, int nblk, int nblk2, int step,
                                                    const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
-                                                   const int* __restrict__ flags, long sF_mat, int nchunks, int chunk0) {
+                                                   const int* __restrict__ flags, long sF_mat, int nchunks, int chunk0, int pair0) {
   __shared__ double sq_raw[STAGE_DOUBLES];
-  apply_body<256>(sq_raw, blockIdx.x, blockIdx.y + chunk0, blockIdx.z, Wm, Utm, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat, nchunks);
+  apply_body<256>(sq_raw, blockIdx.x + pair0, blockIdx.y + chunk0, blockIdx.z, Wm, Utm, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat, nchunks);
 }
 
 // The W half alone (the deferred form below): narrower column chunks, or the launch has one workgroup per CU and is latency-bound
 template <int STRIPS>
 __global__ __launch_bounds__(256) void jacb_apply_w(double* __restrict__ Wm, int N, long sM, int nblk, int nblk2, int step,
                                                      const JacState* __restrict__ st, const double* __restrict__ Qt_all, long sQ_mat,
-                                                     const int* __restrict__ flags, long sF_mat) {
+                                                     const int* __restrict__ flags, long sF_mat, int pair0) {
   __shared__ double sq_raw[STAGE_DOUBLES];
-  apply_body<256, STRIPS>(sq_raw, blockIdx.x, blockIdx.y, blockIdx.z, Wm, nullptr, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat,
+  apply_body<256, STRIPS>(sq_raw, blockIdx.x + pair0, blockIdx.y, blockIdx.z, Wm, nullptr, N, sM, nblk, nblk2, step, st, Qt_all, sQ_mat, flags, sF_mat,
                           (int)gridDim.y);
 }
 
@@ -656,14 +676,14 @@ __global__ __launch_bounds__(576) void jacb_eigen_pu(const double* __restrict__ 
                                                       double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
                                                       unsigned long long* __restrict__ offmax, int precheck, int npairs,
                                                       double* __restrict__ Utm, int N, long sM, const double* __restrict__ Qt_prev,
-                                                      const int* __restrict__ flags_prev) {
+                                                      const int* __restrict__ flags_prev, int pair0) {
   __shared__ double stage_raw[STAGE_DOUBLES];
   if ((int)blockIdx.x < npairs) {
-    eigen_p_body(stage_raw, blockIdx.x, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+    eigen_p_body(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
                  offmax, precheck);
   } else {
     const int idx = (int)blockIdx.x - npairs;
-    apply_body<576>(stage_raw, idx % npairs, nchunks + idx / npairs, blockIdx.y, nullptr, Utm, N, sM, nblk, nblk2, step - 1, st, Qt_prev, sQ_mat,
+    apply_body<576>(stage_raw, idx % npairs + pair0, nchunks + idx / npairs, blockIdx.y, nullptr, Utm, N, sM, nblk, nblk2, step - 1, st, Qt_prev, sQ_mat,
                     flags_prev, sF_mat, nchunks);
   }
 }
@@ -690,6 +710,74 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   flags2[1] = reinterpret_cast<int*>(Qt2[1] + (size_t)batch * sQ);
   static const bool no_defer = getenv("ND4HIP_JAC_NO_DEFER") != nullptr;           // A/B switch
   const bool defer = !no_defer && (long)batch * npairs <= 64 && N >= 512;            // see jacb_eigen_pu
+  // Round 3: two chains of launches side by side. The rotation kernel of a step keeps only npairs workgroups busy for ~26 us (issue-
+  // bound on their CUs) while Gram and the W update are throughput kernels; in ONE stream they cannot overlap (a launch that combines
+  // the rotation kernel of one pair group with the Gram / update of another still has the rotation kernel in two of every three
+  // launches). With the block-recursive tournament of jacb_pair the slots [0, npairs/2) and [npairs/2, npairs) of every step are two
+  // closed groups for a whole phase, so each group's Gram -> rotation -> update chain runs on its own stream (chain A on the handle's
+  // stream, chain B on aux_stream) and the rotation kernel of one chain runs beside the throughput kernels of the other. The chains
+  // meet at the three phase ends of a sweep (one event pair each); the step before a meeting applies W and U together (no deferred
+  // U update across a meeting). Single large matrix only.
+  // Measured: 4096^2 317 -> 268 ms; 2048^2 57.5 -> 57.3 and 1024^2 22.6 -> 23.4 ms: there each of the three kernels of a step is ONE wave of
+  // workgroups whose duration does not shrink with half the pairs (Gram 12.2 -> 11.5 us, W update 16.6 -> 18.7, and the rotation kernel
+  // slows from 26 to 35 us when it shares the chip), so a chain's step takes as long as the whole step did. Hence N >= 4096 only
+  // (ND4HIP_JAC_TWO_CHAINS=<min N> moves the threshold, 0 switches it off).
+  static const int two_env = [] { const char* e = getenv("ND4HIP_JAC_TWO_CHAINS"); return e ? atoi(e) : 4096; }();
+  const bool two_off = two_env <= 0;
+  const int two_min_n = two_env > 0 ? two_env : 1 << 30;
+  if (!two_off && defer && batch == 1 && nblk % 4 == 0 && N >= two_min_n) {
+    const int n2 = -nblk, hq = nblk / 2, q = nblk / 4, nsteps = nblk - 1;
+    static const int wstrips_env2 = getenv("ND4HIP_JAC_WSTRIPS") ? atoi(getenv("ND4HIP_JAC_WSTRIPS")) : 0;
+    const int wstrips = wstrips_env2 ? wstrips_env2 : (N <= 2048 ? 1 : 2);
+    hipStream_t chain[2] = {h->stream, h->aux_stream};
+    auto meet = [&]() -> int {                               // both chains wait for each other
+      ND4_HIP(hipEventRecord(h->ev_aux_a, chain[0]));
+      ND4_HIP(hipEventRecord(h->ev_aux_b, chain[1]));
+      ND4_HIP(hipStreamWaitEvent(chain[1], h->ev_aux_a, 0));
+      ND4_HIP(hipStreamWaitEvent(chain[0], h->ev_aux_b, 0));
+      return 0;
+    };
+    // step 0 (all pairs of the 64 rows, intra-block pairs included) on the handle's stream, as in the one-chain form
+    {
+      hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)npairs, (unsigned)nchunks, 1u), dim3(256), 0, chain[0], W, N, sM, nblk, n2, 0, st, Gpart, nchunks, sG, 0);
+      hipLaunchKernelGGL((jacb_eigen<false, 2>), dim3((unsigned)npairs, 1u), dim3(1024), 0, chain[0],
+                         Gpart, nchunks, sG, nblk, n2, 0, st, floor2, tol2, Qt2[0], sQ, flags2[0], sF, offmax, 1, 0);
+      hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)(2 * nchunks), 1u), dim3(256), 0, chain[0],
+                         W, Ut, N, sM, nblk, n2, 0, st, Qt2[0], sQ, flags2[0], sF, nchunks, 0, 0);
+      ND4_HIP(hipEventRecord(h->ev_aux_a, chain[0]));
+      ND4_HIP(hipStreamWaitEvent(chain[1], h->ev_aux_a, 0));
+    }
+    bool prev_full = true;                                   // the previous step applied U itself (nothing deferred)
+    for (int step = 1; step < nsteps; step++) {
+      const bool phase_end = step == hq - 2 || step == hq - 2 + q || step == nsteps - 1;
+      double* Qt = Qt2[step & 1];
+      int* flags = flags2[step & 1];
+      for (int c = 0; c < 2; c++) {
+        const int p0 = c * q;
+        hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)q, (unsigned)nchunks, 1u), dim3(256), 0, chain[c], W, N, sM, nblk, n2, step, st, Gpart, nchunks, sG, p0);
+        if (prev_full)
+          hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)q, 1u), dim3(576), 0, chain[c],
+                             Gpart, nchunks, sG, nblk, n2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, p0);
+        else
+          hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(q + q * nchunks), 1u), dim3(576), 0, chain[c],
+                             Gpart, nchunks, sG, nblk, n2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, q,
+                             Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1], p0);
+        if (phase_end)
+          hipLaunchKernelGGL(jacb_apply, dim3((unsigned)q, (unsigned)(2 * nchunks), 1u), dim3(256), 0, chain[c],
+                             W, Ut, N, sM, nblk, n2, step, st, Qt, sQ, flags, sF, nchunks, 0, p0);
+        else if (wstrips == 1)
+          hipLaunchKernelGGL(jacb_apply_w<1>, dim3((unsigned)q, (unsigned)(N / 64), 1u), dim3(256), 0, chain[c],
+                             W, N, sM, nblk, n2, step, st, Qt, sQ, flags, sF, p0);
+        else
+          hipLaunchKernelGGL(jacb_apply_w<2>, dim3((unsigned)q, (unsigned)((N + 127) / 128), 1u), dim3(256), 0, chain[c],
+                             W, N, sM, nblk, n2, step, st, Qt, sQ, flags, sF, p0);
+      }
+      prev_full = phase_end;
+      if (phase_end) ND4_TRY(meet());
+    }
+    ND4_HIP(hipGetLastError());
+    return 0;
+  }
   for (int step = 0; step < nblk2 - 1; step++) {
     // step 0 of a sweep rotates all pairs of the 64 rows (the pairs inside a block are visited there, once per sweep); the later
     // steps only the 32 x 32 pairs across the two blocks
@@ -711,14 +799,14 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
                            W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
       else
         hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
-                           W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG);
+                           W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG, 0);
       if (cross_only && defer) {
         hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(npairs + npairs * nchunks), (unsigned)batch), dim3(576), 0, h->stream,
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, npairs,
-                           Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1]);
+                           Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1], 0);
       } else if (cross_only) {
         hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)npairs, (unsigned)batch), dim3(576), 0, h->stream,
-                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1);
+                           Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, 0);
       } else if ((long)batch * npairs <= 256) {            // few workgroups: latency matters, 16 waves hide more of it
         hipLaunchKernelGGL((jacb_eigen<false, 2>), dim3((unsigned)npairs, (unsigned)batch), dim3(1024), 0, h->stream,
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, 1, 0);
@@ -733,13 +821,13 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
     const int wstrips = wstrips_env ? wstrips_env : (N <= 2048 ? 1 : 2);
     if (defer && !last && wstrips == 1)
       hipLaunchKernelGGL(jacb_apply_w<1>, dim3((unsigned)npairs, (unsigned)(N / 64), (unsigned)batch), dim3(256), 0, h->stream,
-                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF);
+                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, 0);
     else if (defer && !last && wstrips == 2)
       hipLaunchKernelGGL(jacb_apply_w<2>, dim3((unsigned)npairs, (unsigned)((N + 127) / 128), (unsigned)batch), dim3(256), 0, h->stream,
-                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF);
+                         W, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, 0);
     else
       hipLaunchKernelGGL(jacb_apply, dim3((unsigned)npairs, (unsigned)((defer && !last ? 1 : 2) * nchunks), (unsigned)batch), dim3(256), 0, h->stream,
-                         W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks, 0);
+                         W, Ut, N, sM, nblk, nblk2, step, st, Qt, sQ, flags, sF, nchunks, 0, 0);
   }
   ND4_HIP(hipGetLastError());
   return 0;
