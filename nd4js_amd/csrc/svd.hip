@@ -14,6 +14,7 @@
 // one workgroup per pair; the three inner products use wave shuffle reductions.
 // Rectangular input is reduced to square by QR first (svd_jac_2sided.js:42-52 does the same).
 #include "svd_internal.h"
+#include "dpp.h"
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -226,6 +227,123 @@ __global__ __launch_bounds__(1024) void jac_complete(double* __restrict__ Vm, in
   }
 }
 
+// ---- small matrices (N <= 64): ALL sweeps in one launch, one workgroup per matrix (round 3) ----
+// The driver below costs a launch per round-robin step (or three per block step) and a stream synchronisation every few sweeps: a
+// single 16^2 matrix took 1.0 ms, 64^2 1.5 ms, almost all of it launch and round-trip latency. Here W and Ut live in LDS (rows
+// padded to an odd stride), 8 lanes own a row pair of the current round (32 pairs x 8 lanes = 256 threads; each lane 1/8 of the
+// columns, the three inner products meet by three DPP-free shuffle steps inside the 8 lanes), one barrier per round, and the sweep loop
+// runs on the device until a sweep rotates nothing — the same rule (svd_jac_2sided.js:95-97, :112 in its one-sided form), the same
+// noise floor and the same Rutishauser rotation as jac_step. W and Ut go back to global memory for the common epilogue.
+template <int NMAX>
+__global__ __launch_bounds__(256) void jac_small(double* __restrict__ Wm, double* __restrict__ Utm, int N, long strideM, double tol2,
+                                                  double* __restrict__ floor2_out, unsigned* __restrict__ sweeps_max, unsigned* __restrict__ not_converged,
+                                                  unsigned long long* __restrict__ offmax, unsigned long long* __restrict__ rot_total, int max_sweeps) {
+  constexpr int LD = NMAX + 1;
+  constexpr int C8 = NMAX / 8;                                     // columns per lane
+  __shared__ double s_w[NMAX * LD], s_u[NMAX * LD];
+  __shared__ double s_red[4];
+  __shared__ unsigned s_rot;
+  __shared__ unsigned long long s_off;
+  __shared__ unsigned short s_pair[(NMAX - 1) * 32];               // the tournament, once: p | q << 8 per (step, slot) (two integer divisions each)
+  const int mat = blockIdx.x, t = threadIdx.x, pr = t >> 3, sub = t & 7;
+  double* W = Wm + mat * strideM;
+  double* Ut = Utm + mat * strideM;
+  for (int e = t; e < NMAX * NMAX; e += 256) {
+    const int r = e / NMAX, c = e % NMAX;
+    s_w[r * LD + c] = (r < N && c < N) ? W[(long)r * N + c] : 0.0;
+    s_u[r * LD + c] = (r == c) ? 1.0 : 0.0;
+  }
+  if (t == 0) { s_rot = 0; s_off = 0; }
+  {
+    const int n2s = (N + 1) & ~1;
+    for (int e = t; e < (n2s - 1) * 32; e += 256) {
+      int p = 0, q = 255;
+      if ((e & 31) < n2s / 2) nd4_rr_pair(n2s, e >> 5, e & 31, p, q);
+      s_pair[e] = (unsigned short)(p | (q << 8));
+    }
+  }
+  __syncthreads();
+  // noise floor: (N eps)^2 max_i |w_i|^2 of the input rows (jac_norms + jac_floor)
+  double mx = 0.0;
+  for (int r = t >> 3; r < N; r += 32) {
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < C8; i++) { const double x = s_w[r * LD + sub + 8 * i]; ss += x * x; }
+    ss += nd4dpp::xor1(ss); ss += nd4dpp::xor2(ss); ss += nd4dpp::xor4(ss);
+    mx = fmax(mx, ss);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+  if ((t & 63) == 0) s_red[t >> 6] = mx;
+  __syncthreads();
+  const double fl = tol2 * fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  if (t == 0) floor2_out[mat] = fl;
+  const int n2 = (N + 1) & ~1;
+  int sweeps = 0;
+  unsigned long long rotations = 0;
+  bool converged = N <= 1;
+  unsigned my_rot = 0; double my_off = 0.0;
+  while (!converged && sweeps < max_sweeps) {
+    for (int step = 0; step < n2 - 1; step++) {
+      const unsigned pq = s_pair[step * 32 + pr];
+      const int p = pq & 255, q = pq >> 8;
+      if (q < N) {                                                  // (uniform inside the 8 lanes of a pair)
+        double a[C8], b[C8], ua[C8], ub[C8], aa = 0.0, bb = 0.0, ab = 0.0;
+#pragma unroll
+        for (int i = 0; i < C8; i++) {                              // (the Ut rows are requested with the W rows: one LDS round trip)
+          a[i] = s_w[p * LD + sub + 8 * i]; b[i] = s_w[q * LD + sub + 8 * i];
+          ua[i] = s_u[p * LD + sub + 8 * i]; ub[i] = s_u[q * LD + sub + 8 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < C8; i++) { aa += a[i] * a[i]; bb += b[i] * b[i]; ab += a[i] * b[i]; }
+        // the 8 lanes of a pair sit in one DPP row: cross-lane adds at VALU speed (a ds_bpermute butterfly is ~100 cycles per step)
+        aa += nd4dpp::xor1(aa); bb += nd4dpp::xor1(bb); ab += nd4dpp::xor1(ab);
+        aa += nd4dpp::xor2(aa); bb += nd4dpp::xor2(bb); ab += nd4dpp::xor2(ab);
+        aa += nd4dpp::xor4(aa); bb += nd4dpp::xor4(bb); ab += nd4dpp::xor4(ab);
+        if (aa > fl && bb > fl && ab * ab > tol2 * aa * bb) {
+          // few-ulp reciprocals / reciprocal square roots (as in svd_block.hip): s and tau = s / (1 + c) only have to be mutually
+          // consistent to a few ulp; two sqrt and three divisions were ~175 dependent instructions per round
+          const double zeta = (bb - aa) * 0.5 * nd4dpp::fast_rcp(ab);
+          const double z1 = 1.0 + zeta * zeta;
+          const double tn = copysign(nd4dpp::fast_rcp(fabs(zeta) + z1 * nd4dpp::fast_rsqrt(z1)), zeta);
+          const double c = nd4dpp::fast_rsqrt(1.0 + tn * tn), sn = c * tn, tau = sn * nd4dpp::fast_rcp(1.0 + c);
+#pragma unroll
+          for (int i = 0; i < C8; i++) {
+            s_w[p * LD + sub + 8 * i] = a[i] - sn * (b[i] + tau * a[i]);
+            s_w[q * LD + sub + 8 * i] = b[i] + sn * (a[i] - tau * b[i]);
+            s_u[p * LD + sub + 8 * i] = ua[i] - sn * (ub[i] + tau * ua[i]);
+            s_u[q * LD + sub + 8 * i] = ub[i] + sn * (ua[i] - tau * ub[i]);
+          }
+          my_rot += 1u;                                              // (counted per pair leader at the sweep's end: no LDS atomics in the rounds)
+          my_off = fmax(my_off, (ab * ab) * nd4dpp::fast_rcp(aa * bb));
+        }
+      }
+      __syncthreads();
+    }
+    sweeps++;
+    if (sub == 0 && my_rot) { atomicAdd(&s_rot, my_rot); atomicMax(&s_off, (unsigned long long)__double_as_longlong(my_off)); }
+    my_rot = 0;
+    __syncthreads();
+    const unsigned r = s_rot;
+    __syncthreads();
+    if (t == 0) s_rot = 0;
+    rotations += r;
+    converged = r == 0;
+    __syncthreads();
+  }
+  for (int e = t; e < N * N; e += 256) {
+    const int r = e / N, c = e % N;
+    W[e] = s_w[r * LD + c];
+    Ut[e] = s_u[r * LD + c];
+  }
+  if (t == 0) {
+    atomicMax(sweeps_max, (unsigned)sweeps);
+    if (!converged) atomicAdd(not_converged, 1u);
+    atomicMax(offmax, s_off);
+    atomicAdd(rot_total, rotations);
+  }
+}
+
 // W (N x N, batch) holds the input and is destroyed. Outputs U, sv, V (dense, N x N / N).
 int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, double* sv, double* V,
                   int* sweeps_out, double* offnorm_out) {
@@ -241,7 +359,9 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   static const bool noblock = getenv("ND4HIP_SVD_NOBLOCK") != nullptr;
   static const bool precheck_always = getenv("ND4HIP_JAC_PRECHECK_ALWAYS") != nullptr;
   static const bool debug = getenv("ND4HIP_SVD_DEBUG") != nullptr;
-  const bool blocked = N >= 16 && !noblock;      // below 16 the row-pair kernel is fine (a few microseconds per matrix)
+  static const bool small_off = getenv("ND4HIP_SVD_NO_SMALL") != nullptr;
+  const bool small = !small_off && N > 1 && N <= 64;              // all sweeps in one launch (jac_small)
+  const bool blocked = N >= 16 && !noblock && !small;             // (without jac_small: below 16 the row-pair kernel)
   const int Np = blocked ? ((N + 63) / 64) * 64 : N;
   const bool padded = Np != N;
   const long sMp = (long)Np * Np;
@@ -269,7 +389,7 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
   unsigned* h_active = static_cast<unsigned*>(pin);
   unsigned long long* h_off = reinterpret_cast<unsigned long long*>(h_active + 2);
 
-  ND4_TRY(nd4_set_identity(h, N, N, Ut, N, batch, sM));
+  if (!small) ND4_TRY(nd4_set_identity(h, N, N, Ut, N, batch, sM));
   ND4_HIP(hipMemsetAsync(st, 0, sizeof(JacState) * batch + 32, h->stream));
   if (padded) {
     ND4_HIP(hipMemsetAsync(Wp, 0, sizeof(double) * (size_t)batch * sMp, h->stream));
@@ -281,12 +401,26 @@ int jacobi_square(nd4hip_handle* h, int batch, int N, double* W, double* U, doub
 
   const int n2 = (N + 1) & ~1;
   const double eps = 0x1p-52, tol = N * eps, tol2 = tol * tol;
-  hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
-  hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, svr, N, tol2, floor2);
+  if (!small) {
+    hipLaunchKernelGGL(jac_norms, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, h->stream, W, N, sM, svr);
+    hipLaunchKernelGGL(jac_floor, dim3((unsigned)batch), dim3(256), 0, h->stream, svr, N, tol2, floor2);
+  }
   int sweeps = 0;
   unsigned long long last_off = 0, rot_seen = 0;
   // the first sweep of a large matrix rotates (nearly) every pair; afterwards the rotation count of the last sweep decides
   bool dense_phase = blocked && Np >= 512 && !precheck_always;
+  if (small) {
+    // all sweeps in ONE launch, one workgroup per matrix (jac_small); sweeps_max lives in the word behind `active`
+    ND4_HIP(hipMemsetAsync(active, 0, 16, h->stream));
+    if (N <= 32) hipLaunchKernelGGL(jac_small<32>, dim3((unsigned)batch), dim3(256), 0, h->stream, W, Ut, N, sM, tol2, floor2, active + 1, active, offmax, rot_total, MAX_SWEEPS);
+    else         hipLaunchKernelGGL(jac_small<64>, dim3((unsigned)batch), dim3(256), 0, h->stream, W, Ut, N, sM, tol2, floor2, active + 1, active, offmax, rot_total, MAX_SWEEPS);
+    ND4_HIP(hipGetLastError());
+    ND4_HIP(hipMemcpyAsync(h_active, active, 24, hipMemcpyDeviceToHost, h->stream));
+    ND4_HIP(hipStreamSynchronize(h->stream));
+    sweeps = (int)h_active[1];
+    last_off = *h_off;
+    if (h_active[0] != 0) sweeps = MAX_SWEEPS;                        // some matrix did not converge
+  } else
   if (N > 1) {
     for (;;) {
       ND4_HIP(hipMemsetAsync(active, 0, 16, h->stream));            // active + offmax (the rotation total runs on)

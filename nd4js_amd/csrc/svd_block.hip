@@ -722,7 +722,8 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   // workgroups whose duration does not shrink with half the pairs (Gram 12.2 -> 11.5 us, W update 16.6 -> 18.7, and the rotation kernel
   // slows from 26 to 35 us when it shares the chip), so a chain's step takes as long as the whole step did. Hence N >= 4096 only
   // (ND4HIP_JAC_TWO_CHAINS=<min N> moves the threshold, 0 switches it off).
-  static const int two_env = [] { const char* e = getenv("ND4HIP_JAC_TWO_CHAINS"); return e ? atoi(e) : 4096; }();
+  const char* two_e = getenv("ND4HIP_JAC_TWO_CHAINS");      // (read per sweep, not cached: the tests move the threshold)
+  const int two_env = two_e ? atoi(two_e) : 4096;
   const bool two_off = two_env <= 0;
   const int two_min_n = two_env > 0 ? two_env : 1 << 30;
   if (!two_off && defer && batch == 1 && nblk % 4 == 0 && N >= two_min_n) {
