@@ -137,6 +137,18 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
         e.update({"ms_min": round(ms3[1], 2), "ms_max": round(ms3[2], 2), "timing": "median of 10 (HIP events)"})
         e["checks"] = svd_checks(dev, A9, N)
         out["svd%d" % N] = e
+        # small problems (VERDICT r2 #7a): all sweeps of an N <= 64 matrix in ONE launch (jac_small), device-resident
+        try:
+            S1 = dev.fill_uniform(31, (32, 32))
+            SB = dev.fill_uniform(32, (8192, 32, 32))
+            m1 = _median_ms(lambda: dev.svd_decomp(S1), h, reps=20, warm=3)
+            mb = _median_ms(lambda: dev.svd_decomp(SB), h, reps=5, warm=1)
+            out["svd_small"] = {"single_32x32_us": round(m1[0] * 1e3, 1), "batch_8192x32x32_ms": round(mb[0], 3),
+                                "us_per_matrix_batched": round(mb[0] * 1e3 / 8192, 3), "timing": "median (HIP events), device-resident",
+                                "kernel": "jac_small<32> (one workgroup per matrix, all sweeps) + the common epilogue launches"}
+            del S1, SB
+        except Exception as ex:  # pragma: no cover
+            out["svd_small"] = {"error": repr(ex)}
         # QR panel (north_star: >= 50 % of HBM peak "on the QR panel"): geqr2 + larft of 16 columns, one workgroup per matrix;
         # algorithmic bytes = 16 m b (each panel element read once and written once)
         try:

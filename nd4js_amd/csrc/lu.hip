@@ -104,9 +104,13 @@ __global__ void lu_panel_global(double* __restrict__ LU, int N, long strideM, in
 // Per column: one reciprocal + a residual correction and W-1-k FMAs per row, no cross-lane traffic in the update; the arg-max is a DPP
 // wave reduction + T/64 LDS partials that every thread finishes itself (no second barrier); the pivot row and the displaced
 // row travel through LDS. The column loop is expanded at compile time, so every register index is static. 2 barriers per column.
+// stage != nullptr (look-ahead form, round 3): the panel's columns come from the contiguous block lu_narrow_fused has left behind
+// ([N - j0 rows][16], already interchanged and updated by the previous panel), and the 16 x 16 block of U above the panel
+// (stage_top) is copied into place on the way.
 template <int R, int W, int T>
 __device__ __forceinline__ void lu_panel_row_body(const int mat, double* __restrict__ LU, int N, long strideM, int j0, int nb,
-                                                  int32_t* __restrict__ ipiv, int nopivot) {
+                                                  int32_t* __restrict__ ipiv, int nopivot, const double* __restrict__ stage = nullptr,
+                                                  const double* __restrict__ stage_top = nullptr) {
   constexpr int NWV = T / 64;
   static_assert(NWV == 8 || NWV == 16, "8 or 16 waves");
   __shared__ PivCand s_red[NWV];
@@ -121,8 +125,8 @@ __device__ __forceinline__ void lu_panel_row_body(const int mat, double* __restr
 #pragma unroll
     for (int c = 0; c < W; c++) a[i][c] = 0.0;
     if (r < N) {
-      const double* src = A + (long)r * N + j0;
-      if (nb == W && (N & 1) == 0) {                    // 16-byte loads: each lane reads its own 128-B row segment
+      const double* src = stage != nullptr ? stage + (long)(r - j0) * W : A + (long)r * N + j0;
+      if (nb == W && ((N & 1) == 0 || stage != nullptr)) {   // 16-byte loads: each lane reads its own 128-B row segment
 #pragma unroll
         for (int c = 0; c < W; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
       } else {
@@ -131,6 +135,7 @@ __device__ __forceinline__ void lu_panel_row_body(const int mat, double* __restr
       }
     }
   }
+  if (stage_top != nullptr && t < NB * NB) A[(long)(j0 - NB + t / NB) * N + j0 + t % NB] = stage_top[t];   // U12 of the previous panel for these columns
   // The column loop is expanded at compile time (a generic lambda called with integral constants), not by the loop unroller:
   // the DPP cross-lane moves are convergent operations, a loop that contains them is only unrolled late, after the pass that
   // splits the register tile into scalars has run, and the tile would then live in scratch memory.
@@ -381,8 +386,13 @@ __device__ __forceinline__ void lu_update_block(int b, int mat, double* __restri
 // panel at j0 (workgroup 0 of a matrix) together with everything the previous panel (at pj0) still owes the other columns
 template <int R>
 __global__ __launch_bounds__(512) void lu_panel_row_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ P,
-                                                        int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0) {
-  if (blockIdx.x == 0) { lu_panel_row_body<R, NB, 512>(blockIdx.y, LU, N, strideM, j0, NB, ipiv, nopivot); return; }
+                                                        int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0,
+                                                        const double* __restrict__ stage, long strideStage) {
+  if (blockIdx.x == 0) {
+    const double* sg = stage != nullptr ? stage + blockIdx.y * strideStage : nullptr;
+    lu_panel_row_body<R, NB, 512>(blockIdx.y, LU, N, strideM, j0, NB, ipiv, nopivot, sg != nullptr ? sg + NB * NB : nullptr, sg);
+    return;
+  }
   lu_update_block<512, true>((int)blockIdx.x - 1, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P);
 }
 // the same update work on its own (the last look-ahead panel's debt)
@@ -427,6 +437,95 @@ __global__ __launch_bounds__(256) void lu_narrow_gemm(double* __restrict__ LU, i
     for (int r = 0; r < 4; r++) {
       const int rc = rt + q * 16 + fk + 4 * r;
       if (rc < m2 && cok) Cp[(long)rc * N + fx] = c[q][r];
+    }
+  }
+}
+
+// Round 3: lu_narrow_top + lu_narrow_gemm in ONE launch, out of place. Every workgroup (256 rows of the part below the panel's top
+// block) works out the interchanges for itself (the gather trick of lu_colblock_update on 32 rows), gathers the 16 x 16 block above
+// the next panel as it stands after them, solves U12 = L11^-1 A12 (16 threads, the order of lu.js:71-72), and updates its own rows,
+// read from where the interchanges take them from: a row below the top block only ever receives the content of one of the 16 top rows
+// (a pivot row trades places with a top row; a top row with another top row), so nobody reads a row that another workgroup writes —
+// as long as NOTHING is written in place: the results go to a contiguous stage ([0, 256): U12; then [N - c0 rows][16]: the next
+// panel's columns), from which the next panel loads its tile and puts U12 into place. One dependent launch per panel less.
+__global__ __launch_bounds__(256) void lu_narrow_fused(const double* __restrict__ LU, int N, long strideM, const int32_t* __restrict__ ipiv,
+                                                        int nopivot, int pj0, double* __restrict__ stage, long strideStage) {
+  __shared__ int s_piv[NB], s_src[2 * NB], s_dst[2 * NB], s_map[256];
+  __shared__ double s_top[NB][NB + 1], s_l[NB][NB + 1];
+  const double* A = LU + blockIdx.y * strideM;
+  const int32_t* ip = ipiv + (long)blockIdx.y * N;
+  double* out = stage + blockIdx.y * strideStage;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int c0 = pj0 + NB;                                      // the next panel's first row and column
+  const int m2 = N - c0, r0 = (int)blockIdx.x * 256;           // this workgroup: rows c0 + r0 .. + 255
+  if (t < NB) s_piv[t] = nopivot ? pj0 + t : ip[pj0 + t];
+  {
+    const int i = t / NB, j = t % NB;
+    s_l[i][j] = (j < i) ? A[(long)(pj0 + i) * N + pj0 + j] : 0.0;
+    s_map[t] = c0 + r0 + t;
+  }
+  __syncthreads();
+  if (t < 2 * NB) {
+    const int k = t & (NB - 1);
+    const int dst = t < NB ? pj0 + k : s_piv[k];
+    int pos = dst;
+#pragma unroll
+    for (int q = NB - 1; q >= 0; q--) {
+      const int ps = s_piv[q];
+      pos = (pos == pj0 + q) ? ps : ((pos == ps) ? pj0 + q : pos);
+    }
+    s_src[t] = pos;
+    s_dst[t] = (t < NB || dst >= pj0 + NB) ? dst : -1;
+  }
+  __syncthreads();
+  if (t >= NB && t < 2 * NB) {                                 // pivot rows below the top block that fall into this workgroup's range
+    const int d = s_dst[t] - (c0 + r0);
+    if (s_dst[t] >= 0 && d >= 0 && d < 256) s_map[d] = s_src[t];
+  }
+  {
+    const int k = t / NB, c = t % NB;
+    s_top[k][c] = A[(long)s_src[k] * N + c0 + c];
+  }
+  __syncthreads();
+  if (t < NB) {                                                 // U12 = L11^-1 A12, one thread per column
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) x[i] = s_top[i][t];
+#pragma unroll
+    for (int i = 1; i < NB; i++) {
+      double acc = x[i];
+#pragma unroll
+      for (int j = 0; j < i; j++) acc -= s_l[i][j] * x[j];
+      x[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) { s_top[i][t] = x[i]; if (blockIdx.x == 0) out[i * NB + t] = x[i]; }
+  }
+  __syncthreads();
+  const int rt = r0 + wave * 64;
+  const double* Lp = A + (long)c0 * N + pj0;
+  double bw[4], av[4][4]; d4 c[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = -s_top[kk * 4 + fk][fx];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = rt + q * 16 + fx;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < m2) ? Lp[(long)ra * N + kk * 4 + fk] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      c[q][r] = (rc < m2) ? A[(long)s_map[rc - r0] * N + c0 + fx] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rc = rt + q * 16 + fk + 4 * r;
+      if (rc < m2) out[NB * NB + (long)rc * NB + fx] = c[q][r];
     }
   }
 }
@@ -561,19 +660,32 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   if (!la_off && N <= 2048 && N >= 64 + NB && p_in_laswp) {
     int pj0 = -1;
     int j0 = 0;
+    void* stg = nullptr;
+    const long sStage = (long)NB * NB + (long)N * NB;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sStage, &stg));
+    double* stage = static_cast<double*>(stg);
+    static const bool fuse_off = [] { const char* e = getenv("ND4HIP_LU_NO_FUSED_NARROW"); return e && *e && *e != '0'; }();
+    const bool fused = !fuse_off && (N & 1) == 0;
     for (; N - j0 >= 64; j0 += NB) {
       const int m = N - j0;
-      // the panel at pj0 has reached its own columns and the 16 behind them (narrow launches: [pj0 + NB, pj0 + 2 NB) = this panel);
-      // it still owes the columns from pj0 + 2 NB on, the columns left of it, and P
+      // the panel at pj0 has reached its own columns and the 16 behind them (the narrow launch: [pj0 + NB, pj0 + 2 NB) = this panel,
+      // staged out of place by lu_narrow_fused); it still owes the columns from pj0 + 2 NB on, the columns left of it, and P
       const int wide0 = pj0 + 2 * NB;
       const int nupd = pj0 < 0 ? 0 : 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
       const dim3 grid((unsigned)(1 + nupd), (unsigned)batch);
-      if (m <= 512)       hipLaunchKernelGGL(lu_panel_row_la<1>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
-      else if (m <= 1024) hipLaunchKernelGGL(lu_panel_row_la<2>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
-      else                hipLaunchKernelGGL(lu_panel_row_la<4>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0);
+      const double* sg = (fused && pj0 >= 0) ? stage : nullptr;
+      if (m <= 512)       hipLaunchKernelGGL(lu_panel_row_la<1>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
+      else if (m <= 1024) hipLaunchKernelGGL(lu_panel_row_la<2>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
+      else                hipLaunchKernelGGL(lu_panel_row_la<4>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
       const int c0 = j0 + NB;                                // the next panel's columns
-      hipLaunchKernelGGL(lu_narrow_top, dim3((unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, ipiv, nopivot, j0, c0);
-      hipLaunchKernelGGL(lu_narrow_gemm, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, LU, N, strideM, j0, c0);
+      const bool more = N - c0 >= 64;                        // another look-ahead panel follows: stage its columns out of place
+      if (fused && more) {
+        hipLaunchKernelGGL(lu_narrow_fused, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                           LU, N, strideM, ipiv, nopivot, j0, stage, sStage);
+      } else {
+        hipLaunchKernelGGL(lu_narrow_top, dim3((unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, ipiv, nopivot, j0, c0);
+        hipLaunchKernelGGL(lu_narrow_gemm, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, LU, N, strideM, j0, c0);
+      }
       pj0 = j0;
     }
     {   // the last look-ahead panel's debt, then the remaining (short) panels the old way
