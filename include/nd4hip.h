@@ -210,8 +210,11 @@ int nd4hip_dgesvdj_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64
 /* ---- one Householder panel on its own: geqr2 + larft of a 16-column panel (the inner step of qr_decomp, src/la/qr.js:54-68
  * eliminates the same entries column by column with Givens rotations) ---------------------------------------------
  * A [batch,M,16] (1 <= M <= 2048) is overwritten with R in its top 16 x 16 (entries below the diagonal are left as the kernel
- * leaves them); V [batch,M,16] receives the explicit unit-lower reflectors, T [batch,16,16] the compact-WY factor
- * (Q_panel = I - V T V^T). Device pointers. Exposed for the panel roofline of bench.py (16 M b bytes per panel). */
+ * leaves them); V [batch,M,16] receives the panel's reflector block, T [batch,16,16] its factor: Q_panel = I - V T V^T is
+ * orthogonal and Q_panel^T A = [R; 0]. Batches of more than 8 panels (and panels of fewer than 64 rows) take the thread-per-row
+ * Householder kernel: V explicit unit lower trapezoidal, T upper triangular (compact WY). Up to 8 panels take the row-split form
+ * (CholeskyQR2 + a compact orthogonal completion, three launches): V = Q - [S; 0] with a full top block, T a full 16 x 16 matrix.
+ * Device pointers. Exposed for the panel roofline of bench.py (16 M b bytes per panel). */
 int nd4hip_dgeqr2_panel_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t b, double* A, double* V, double* T);
 
 /* Executed-work audit of the LAST nd4hip_dgesvdj_batched[_dev] call on this handle ("must print sweeps and

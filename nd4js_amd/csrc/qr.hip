@@ -2122,10 +2122,30 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
 int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, double* T) {
   Nd4WsScope scope(h);
   void* p = nullptr;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NB, &p));
+  const int parts = (M + NB + 511) / 512 + 1;
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (NB + (2 * parts + 1) * 256 + 256 + 2) + 64, &p));
   double* taus = static_cast<double*>(p);
   const long sW = (long)M * NB;
   const int nb = M < NB ? M : NB;
+  static const bool hr_off = [] { const char* e = getenv("ND4HIP_QR_NO_HR"); return e && *e && *e != '0'; }();
+  if (!hr_off && batch <= 8 && M >= HR_MIN_ROWS) {
+    // few panels: the row-split form (three launches, the rows over workgroups of 512): V = Q - [S; 0] and T = K of qrh_reconstruct
+    QrhHost hr;
+    hr.h = h; hr.batch = batch; hr.nq = 0; hr.V = V; hr.T = T; hr.ldv = NB; hr.sV = sW; hr.sT = NB * NB;
+    QrhP& P = hr.P;
+    double* d = taus + (size_t)batch * NB;
+    P.Wm = A; P.M = M; P.N = NB; P.ld = NB; P.strideW = sW; P.Vall = V; P.ldv = NB; P.strideV = sW; P.Tall = T; P.strideT = NB * NB;
+    P.taus = taus; P.strideTau = NB; P.Xp = nullptr; P.strideXp = 0;
+    P.Gp = d; P.strideGp = (long)(parts + 1) * 256; d += (size_t)batch * P.strideGp;
+    P.G2p = d; P.strideG2 = (long)parts * 256; d += (size_t)batch * P.strideG2;
+    P.R1 = d; d += (size_t)batch * 256;
+    P.flag = reinterpret_cast<int*>(d);
+    P.QT = nullptr; P.strideQT = 0; P.nxp = 0; P.Xs = nullptr; P.strideXs = 0;
+    P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 1; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
+    P.stamps = nullptr; P.stamp_slot = 0;
+    ND4_TRY(hr.panel(0, NB, false, true));
+    return 0;
+  }
   if (M <= 512)       launch_panel_row<1>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
   else if (M <= 1024) launch_panel_row<2>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
   else                launch_panel_row<4>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
