@@ -256,6 +256,256 @@ __global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N
   lu_panel_row_body<R, W, T>(blockIdx.x, LU, N, strideM, j0, nb, ipiv, nopivot);
 }
 
+// ---- panels taller than one workgroup's registers: the rows over P co-resident workgroups, ONE exchange per column (round 3) ----
+// Partial pivoting needs the arg-max over ALL rows below the diagonal for every column (lu.js:48-52), so a panel whose rows are
+// spread over workgroups needs one all-to-all per column. Done with fences (release: write back the L2, acquire: invalidate it) such
+// an exchange costs 2-18 us on this chip; done with agent-scope relaxed atomics only (sc1 stores are written through, sc1 loads
+// miss the non-coherent caches: no write-back, no invalidate) it costs 1.3-1.7 us for P <= 16, also with the rest of the chip
+// streaming through the same L2s (tools/xwg_lat.hip) — less than one kernel boundary. Each memory hop of such an exchange is
+// 0.4-1 us, so the protocol has two (store -> load), not four (store, wait, flag -> poll -> payload): every 8-byte word that
+// crosses carries 32 bits of payload and a 32-bit tag (the global column number + 1), i.e. a double travels as two single-copy-atomic
+// words and is valid as soon as both tags match: no flag, no s_waitcnt, no ordering between words needed. Per column k:
+//   every wave: arg-max of its rows (DPP), its candidate and the candidate's 16-value row segment into LDS; barrier;
+//   wave 0:     the workgroup's candidate -> its slot (row segment, magnitude, row number; workgroup 0 also the current row jc,
+//               which the pivot row displaces); then it polls all P slots (ONE polling wave per workgroup: eight waves polling
+//               the same lines doubled every hop), finds the winner (largest magnitude, ties -> lowest row: the first maximum of
+//               lu.js:50-52, exactly as inside one workgroup) and leaves pivot row, displaced row and pivot row number in LDS; barrier;
+//   every wave: eliminates its rows; the thread that owns the pivot row takes the displaced row jc, thread k of workgroup 0 (the
+//               owner of row jc) the pivot row.
+// The slots alternate by column parity: a workgroup publishes column k + 2 only after it has read every other workgroup's column
+// k + 1, which those publish after reading column k. The slots are cleared once per call (a tag never repeats inside one
+// factorisation). Every spin is bounded: a stuck exchange (cannot happen while the P workgroups are co-resident: P * batch <= 64
+// here) raises *stuck, every workgroup leaves, and lu_mw_poison marks the permutation vector invalid.
+constexpr int MW_SLOT = 128;                      // 8-byte words per slot; value v = words 2v, 2v+1: [0,16) candidate row, 16 magnitude, 17 row number, [18,34) row jc
+constexpr int MW_MAXP = 16;
+constexpr long MW_STRIDE = 2l * MW_MAXP * MW_SLOT;   // per matrix: [parity][workgroup] slots (in doubles == words)
+constexpr int MW_SPIN_LIMIT = 1 << 21;
+typedef unsigned long long mw_u64;
+
+__device__ __forceinline__ void mw_st(mw_u64* slot, int v, double x, unsigned tag) {
+  const mw_u64 bits = (mw_u64)__double_as_longlong(x), tg = (mw_u64)tag << 32;
+  __hip_atomic_store(slot + 2 * v, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot + 2 * v + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double mw_ld(const mw_u64* slot, int v, unsigned tag, bool& ok) {
+  const mw_u64 w0 = __hip_atomic_load(slot + 2 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const mw_u64 w1 = __hip_atomic_load(slot + 2 * v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
+  return __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+}
+
+template <int R, int PQ, bool STAMPS = false>
+__global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ ipiv,
+                                                   int nopivot, double* __restrict__ xbuf, int* __restrict__ stuck, int P,
+                                                   unsigned long long* __restrict__ stamps = nullptr) {
+  constexpr int T = 512, W = NB, RT = R * T, NWV = 8;
+  __shared__ PivCand s_red[NWV];
+  __shared__ double s_rows[NWV][W], s_j[W], s_u[W], s_dj[W];
+  __shared__ int s_piv;
+  const int w = blockIdx.x, mat = blockIdx.y;
+  double* A = LU + mat * strideM;
+  int32_t* ip = ipiv + (long)mat * N;
+  mw_u64* slots = reinterpret_cast<mw_u64*>(xbuf + mat * MW_STRIDE);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rbase = j0 + w * RT;                  // first row of this workgroup; row of (thread t, slot i) = rbase + t + T * i
+  const bool vec = (N & 1) == 0;
+  double a[R][W];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = rbase + t + T * i;
+#pragma unroll
+    for (int c = 0; c < W; c++) a[i][c] = 0.0;
+    if (r < N) {
+      const double* src = A + (long)r * N + j0;
+      if (vec) {
+#pragma unroll
+        for (int c = 0; c < W; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) a[i][c] = src[c];
+      }
+    }
+  }
+  auto column = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int jc = j0 + k, tag = jc + 1;
+    // debug stamps (ND4HIP_LU_STAMPS): [workgroup][wave][column][phase] shader clocks of lane 0
+    auto stamp = [&](int ph) { if constexpr (STAMPS) { if (lane == 0 && mat == 0) stamps[(((long)w * NWV + wave) * W + k) * 8 + ph] = __builtin_amdgcn_s_memtime(); } };
+    stamp(0);
+    mw_u64* myslot = slots + ((long)(k & 1) * MW_MAXP + w) * MW_SLOT;
+    const mw_u64* sl = slots + (long)(k & 1) * MW_MAXP * MW_SLOT;
+    // ---- this wave's candidate ----
+    PivCand cand{-2.0, 0x7fffffff};
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const int r = rbase + t + T * i;
+      PivCand o{pivot_mag(a[i][k], r, jc), r};
+      if (nopivot) o.mag = (r == jc) ? DBL_MAX * 2.0 : -2.0;
+      if ((w == 0 && i == 0 && t < k) || r >= N) o.mag = -2.0;
+      cand = better(cand, o);
+    }
+    const double wm = nd4dpp::wave_max(cand.mag);
+    const int wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
+    if (lane == 0) { s_red[wave].mag = wm; s_red[wave].idx = wi; }
+#pragma unroll
+    for (int i = 0; i < R; i++)
+      if (rbase + t + T * i == wi) {
+#pragma unroll
+        for (int c = 0; c < W; c++) s_rows[wave][c] = a[i][c];
+      }
+    if (w == 0 && t == k) {
+#pragma unroll
+      for (int c = 0; c < W; c++) s_j[c] = a[0][c];
+    }
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+    if (wave == 0) {
+      // ---- publish the workgroup's candidate ----
+      const PivCand c8 = s_red[lane & (NWV - 1)];
+      double bm = fmax(c8.mag, nd4dpp::xor1(c8.mag)); bm = fmax(bm, nd4dpp::xor2(bm)); bm = fmax(bm, nd4dpp::xor4(bm));
+      int bi = c8.mag == bm ? c8.idx : 0x7fffffff;
+      bi = min(bi, nd4dpp::xor1(bi)); bi = min(bi, nd4dpp::xor2(bi)); bi = min(bi, nd4dpp::xor4(bi));
+      const int ww = (((bi - rbase) & (T - 1)) >> 6) & (NWV - 1);
+      if (lane < W) mw_st(myslot, lane, s_rows[ww][lane], (unsigned)tag);
+      else if (lane == 16) mw_st(myslot, 16, bm, (unsigned)tag);
+      else if (lane == 17) mw_st(myslot, 17, __longlong_as_double((long long)bi), (unsigned)tag);
+      else if (w == 0 && lane >= 32 && lane < 32 + W) mw_st(myslot, 18 + (lane - 32), s_j[lane - 32], (unsigned)tag);
+      stamp(3);
+      // ---- all candidates at once, until every word carries this column's tag: lanes 0..15 magnitude + row number of workgroup
+      //      `lane`, lanes 32..47 the displaced row jc, and the P row segments 16 lanes each ----
+      // Three polls in flight, a few hundred cycles apart (loads return in order, so the first is examined while the others are
+      // still under way): the exchange is seen ~ one stagger after it lands instead of up to one memory round trip (~1000 cycles) later.
+      double m1 = -3.0, m2 = 0.0, rowsv[PQ];
+      // (branch-free: every lane loads from a valid address — lanes without a job of their own repeat a neighbour's — so that all
+      //  loads of a poll are in flight together; with the loads under divergent branches the compiler waits for each in turn)
+      const bool l_dj = lane >= 32 && lane < 32 + W;
+      const int gl = (lane & 15) < P ? (lane & 15) : P - 1;
+      const mw_u64* p1 = l_dj ? sl + 2 * (18 + (lane - 32)) : sl + (long)gl * MW_SLOT + 2 * 16;
+      const mw_u64* p2 = sl + (long)gl * MW_SLOT + 2 * 17;
+      const mw_u64* pr[PQ];
+#pragma unroll
+      for (int q = 0; q < PQ; q++) {
+        const int g = q * 4 + (lane >> 4);
+        pr[q] = sl + (long)(g < P ? g : P - 1) * MW_SLOT + 2 * (lane & 15);
+      }
+      constexpr int NWD = 2 * (2 + PQ);
+      auto issue = [&](mw_u64 (&wd)[NWD]) {
+        wd[0] = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wd[1] = __hip_atomic_load(p1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wd[2] = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wd[3] = __hip_atomic_load(p2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < PQ; q++) {
+          wd[4 + 2 * q] = __hip_atomic_load(pr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wd[5 + 2 * q] = __hip_atomic_load(pr[q] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
+      // (the empty asm pins the examination of a poll behind the branch on the previous one: otherwise all three are examined —
+      //  i.e. waited for — before the first branch)
+      auto good = [&](mw_u64 (&wd)[NWD]) -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NWD; i++) { asm volatile("" : "+v"(wd[i])); ok = ok && (unsigned)(wd[i] >> 32) == (unsigned)tag; }
+        return __builtin_amdgcn_ballot_w64(!ok) == 0;
+      };
+      auto val = [&](const mw_u64 (&wd)[NWD], int v) -> double {
+        return __longlong_as_double((long long)((wd[2 * v + 1] << 32) | (wd[2 * v] & 0xffffffffull)));
+      };
+      auto take = [&](const mw_u64 (&wd)[NWD]) {
+        m1 = val(wd, 0); m2 = val(wd, 1);
+#pragma unroll
+        for (int q = 0; q < PQ; q++) rowsv[q] = val(wd, 2 + q);
+      };
+      {
+        mw_u64 wa[NWD], wb[NWD], wc[NWD];
+        issue(wa); __builtin_amdgcn_s_sleep(3); issue(wb); __builtin_amdgcn_s_sleep(3); issue(wc);
+        int spins = 0;
+        for (;;) {
+          if (good(wa)) { take(wa); break; }
+          issue(wa);
+          if (good(wb)) { take(wb); break; }
+          issue(wb);
+          if (good(wc)) { take(wc); break; }
+          issue(wc);
+          if (++spins > MW_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); take(wa); break; }
+          if ((spins & 255) == 0 && __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { take(wa); break; }
+        }
+      }
+      stamp(4);
+      double mm = lane < W ? m1 : -3.0;
+      mm = fmax(mm, nd4dpp::xor1(mm)); mm = fmax(mm, nd4dpp::xor2(mm)); mm = fmax(mm, nd4dpp::xor4(mm)); mm = fmax(mm, nd4dpp::xor8(mm));
+      int ii = (lane < P && m1 == mm) ? (int)__double_as_longlong(m2) : 0x7fffffff;
+      ii = min(ii, nd4dpp::xor1(ii)); ii = min(ii, nd4dpp::xor2(ii)); ii = min(ii, nd4dpp::xor4(ii)); ii = min(ii, nd4dpp::xor8(ii));
+      int pv = __builtin_amdgcn_readfirstlane(ii);
+      pv = pv < jc ? jc : (pv > N - 1 ? N - 1 : pv);           // (a stuck exchange must not send later kernels out of bounds)
+      int gw = (pv - j0) / RT; gw = gw > P - 1 ? P - 1 : gw;
+      double sel = rowsv[0];
+#pragma unroll
+      for (int q = 1; q < PQ; q++) sel = (gw >> 2) == q ? rowsv[q] : sel;
+      if ((lane >> 4) == (gw & 3)) s_u[lane & 15] = sel;
+      if (lane >= 32 && lane < 32 + W) s_dj[lane - 32] = m1;
+      if (lane == 0) { s_piv = pv; if (w == 0) ip[jc] = pv; }
+    }
+    __syncthreads();
+    const int piv = s_piv;
+    double u[W];
+#pragma unroll
+    for (int c = 0; c < W; c++) u[c] = s_u[c];
+    stamp(5);
+    if (piv != jc) {
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (rbase + t + T * i == piv) {
+#pragma unroll
+          for (int c = 0; c < W; c++) a[i][c] = s_dj[c];
+        }
+      if (w == 0 && t == k) {
+#pragma unroll
+        for (int c = 0; c < W; c++) a[0][c] = u[c];
+      }
+    }
+    // ---- eliminate below the pivot (same arithmetic as lu_panel_row_body) ----
+    const double pk = u[k];
+    const double apk = fabs(pk);
+    const bool fast = apk >= 0x1p-1000 && apk <= 0x1p1000;
+    const double rk = fast ? nd4dpp::fast_rcp(pk) : 0.0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      if (w > 0 || i > 0 || t > k) {
+        const double q0 = a[i][k] * rk;
+        const double l = fast ? fma(fma(-q0, pk, a[i][k]), rk, q0) : a[i][k] / pk;
+        a[i][k] = l;
+#pragma unroll
+        for (int c = k + 1; c < W; c++) a[i][c] -= l * u[c];
+      }
+    }
+    stamp(6);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define ND4_COL(K) column(std::integral_constant<int, K>{});
+  ND4_COL(0) ND4_COL(1) ND4_COL(2) ND4_COL(3) ND4_COL(4) ND4_COL(5) ND4_COL(6) ND4_COL(7)
+  ND4_COL(8) ND4_COL(9) ND4_COL(10) ND4_COL(11) ND4_COL(12) ND4_COL(13) ND4_COL(14) ND4_COL(15)
+#undef ND4_COL
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = rbase + t + T * i;
+    if (r < N) {
+      double* dst = A + (long)r * N + j0;
+      if (vec) {
+#pragma unroll
+        for (int c = 0; c < W; c += 2) *reinterpret_cast<double2*>(dst + c) = double2{a[i][c], a[i][c + 1]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) dst[c] = a[i][c];
+      }
+    }
+  }
+}
+__global__ void lu_mw_poison(int32_t* __restrict__ P, long total, const int* __restrict__ stuck) {
+  if (*stuck == 0) return;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < total) P[i] = -1;
+}
+
 // ---- look-ahead: everything panel pj0 does to ONE block of <= 16 columns outside it, by ONE workgroup ----
 // The 16 row interchanges, U12 = L11^-1 A12 and A22 -= L21 U12 are all local to a column, so one workgroup can take a block of columns
 // through all three without any other workgroup: the update of the columns BEHIND the next panel then runs in the same launch as the
@@ -655,11 +905,110 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   const bool p_in_laswp = N > NB;
   if (p_in_laswp) hipLaunchKernelGGL(lu_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, (int)N);
   int j_start = 0;
-  // ---- look-ahead form while the panels fit lu_panel_row<R, 16, 512>: see lu_colblock_update ----
+  // Two-level blocking for N > 2048 (round 3): with panels of 8 / 4 columns every step used to read-modify-write the whole trailing
+  // matrix (N^3 / (3 NB) * 16 B: 180 GB at 8192^2 for 366 GFLOP). Now an outer block of 256 columns (ND4HIP_LU_OUTER; 128: 4 % slower, 64: 10 %) is factorised by the same
+  // panel kernels with the rank-NB updates restricted to the block (the interchanges still go to every column at once: two rows per
+  // swap), then U12 = L11^-1 A12 for the whole block row (unit lower, the one-launch solver of trsm.hip on a contiguous
+  // copy) and ONE K = 256 product A22 -= L21 U12 on the tiled MFMA kernel. N <= 2048: one level (nbo = N), as before.
+  static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 256; }();
+  const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : N;
+  void* u12buf = nullptr;
+  if (NBO < N) ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NBO * N, &u12buf));
+  // panels taller than 2048 rows: the rows over P co-resident workgroups of 512 threads x R rows (lu_panel_mw), 16 columns wide
+  static const int mw_r = [] { const char* e = getenv("ND4HIP_LU_MW_R"); return e ? atoi(e) : 4; }();   // 0: off (round 2's split panels)
+  const int mw_rt = (mw_r == 1 ? 1 : mw_r == 2 ? 2 : 4) * 512;
+  const bool mw_on = mw_r != 0 && N > 2048 && (long)batch * ((N + mw_rt - 1) / mw_rt) <= 64 && N <= MW_MAXP * mw_rt;
+  double* xbuf = nullptr; int* stuck = nullptr;
+  if (mw_on) {
+    void* xb = nullptr;
+    const size_t xbytes = sizeof(double) * (size_t)batch * MW_STRIDE + 256;
+    ND4_TRY(nd4_ws_alloc(h, xbytes, &xb));
+    ND4_HIP(hipMemsetAsync(xb, 0, xbytes, h->stream));
+    stuck = static_cast<int*>(xb);
+    xbuf = reinterpret_cast<double*>(static_cast<char*>(xb) + 256);
+  }
+  auto outer_block = [&](const int J, const int bend, const bool two_level) -> int {
+    for (int j0 = J, step = NB; j0 < bend; j0 += step) {
+      const int m = N - j0;
+      // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
+      // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
+      const bool tall8 = m > 2048 && m <= 4096;
+      const bool tall4 = m > 4096 && m <= 8192;
+      const bool mw = mw_on && m > 2048 && bend - j0 >= NB;
+      step = mw ? NB : tall8 ? 8 : tall4 ? 4 : NB;
+      const int nb = bend - j0 < step ? bend - j0 : step;
+      if (mw) {
+        const int Pw = (m + mw_rt - 1) / mw_rt;
+        const dim3 grid((unsigned)Pw, (unsigned)batch);
+#define ND4_MW(RR, PQ) hipLaunchKernelGGL((lu_panel_mw<RR, PQ>), grid, dim3(512), 0, h->stream, LU, N, strideM, j0, ipiv, nopivot, xbuf, stuck, Pw)
+        static const bool stamps_on = [] { const char* e = getenv("ND4HIP_LU_STAMPS"); return e && *e && *e != '0'; }();
+        if (stamps_on && mw_rt == 1024 && Pw <= 4 && j0 == 0) {
+          unsigned long long* st = nullptr; const size_t nst = (size_t)4 * 8 * 16 * 8;
+          ND4_HIP(hipMalloc(&st, nst * 8)); ND4_HIP(hipMemset(st, 0, nst * 8));
+          hipLaunchKernelGGL((lu_panel_mw<2, 1, true>), grid, dim3(512), 0, h->stream, LU, N, strideM, j0, ipiv, nopivot, xbuf, stuck, Pw, st);
+          std::vector<unsigned long long> hs(nst);
+          ND4_HIP(hipStreamSynchronize(h->stream)); ND4_HIP(hipMemcpy(hs.data(), st, nst * 8, hipMemcpyDeviceToHost)); ND4_HIP(hipFree(st));
+          const unsigned long long t0 = hs[0];
+          for (int ww = 0; ww < Pw; ww++) for (int wv = 0; wv < 8; wv += 7) for (int kk = 6; kk < 9; kk++) {
+            fprintf(stderr, "mw stamps wg %d wave %d col %2d:", ww, wv, kk);
+            for (int ph = 0; ph < 7; ph++) fprintf(stderr, " %8lld", (long long)(hs[(((size_t)ww * 8 + wv) * 16 + kk) * 8 + ph] - t0));
+            fprintf(stderr, "\n");
+          }
+        } else
+        if (mw_rt == 2048) { if (Pw <= 4) ND4_MW(4, 1); else if (Pw <= 8) ND4_MW(4, 2); else ND4_MW(4, 4); }
+        else if (mw_rt == 1024) { if (Pw <= 4) ND4_MW(2, 1); else if (Pw <= 8) ND4_MW(2, 2); else ND4_MW(2, 4); }
+        else               { if (Pw <= 4) ND4_MW(1, 1); else if (Pw <= 8) ND4_MW(1, 2); else ND4_MW(1, 4); }
+#undef ND4_MW
+      } else if (tall8) {
+        launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else if (tall4) {
+        launch_panel_row_wt<8, 4, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else if (m >= 64 && m <= 2048) {
+        if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+        else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+        else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
+      } else {
+        int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
+        hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
+      }
+      const int rest = N - j0 - nb;
+      if (N > nb && (!nopivot || rest > 0))
+        hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
+                           LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1, p_in_laswp ? P : (int32_t*)nullptr, bend);
+      const int inner = bend - j0 - nb;                        // columns of the block right of the panel
+      if (rest > 0 && inner > 0) {
+        ND4_HIP(hipGetLastError());
+        ND4_TRY(nd4_gemm(h, false, false, rest, inner, nb, -1.0,
+                         LU + (long)(j0 + nb) * N + j0, N, strideM,
+                         LU + (long)j0 * N + j0 + nb, N, strideM,
+                         1.0, LU + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
+      }
+    }
+    const int far = N - bend, nbo = bend - J;
+    if (far > 0 && two_level) {
+      ND4_HIP(hipGetLastError());
+      double* U12 = static_cast<double*>(u12buf);
+      const long sU = (long)nbo * far;
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, LU + (long)J * N + bend, N, U12, far, batch, strideM, sU));
+      ND4_TRY(nd4_trsm_ld(h, false, true, batch, nbo, far, LU + (long)J * N + J, N, strideM, U12, sU));
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, U12, far, LU + (long)J * N + bend, N, batch, sU, strideM));
+      ND4_TRY(nd4_gemm(h, false, false, far, far, nbo, -1.0, LU + (long)bend * N + J, N, strideM, U12, far, sU,
+                       1.0, LU + (long)bend * N + bend, N, strideM, batch));
+    }
+      return 0;
+  };
+  // phase 1 (N > 2048): outer blocks while the panels are taller than 2048 rows
+  if (NBO < N) {
+    int J = 0;
+    for (; N - J > 2048; J += NBO) ND4_TRY(outer_block(J, J + NBO < N ? J + NBO : N, true));
+    j_start = J;
+  }
+  // ---- look-ahead form once the panels fit lu_panel_row<R, 16, 512> (the whole matrix for N <= 2048, the trailing <= 2048 rows of a
+  //      larger one): see lu_colblock_update ----
   static const bool la_off = [] { const char* e = getenv("ND4HIP_LU_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
-  if (!la_off && N <= 2048 && N >= 64 + NB && p_in_laswp) {
+  if (!la_off && N - j_start <= 2048 && N - j_start >= 64 + NB && p_in_laswp) {
     int pj0 = -1;
-    int j0 = 0;
+    int j0 = j_start;
     void* stg = nullptr;
     const long sStage = (long)NB * NB + (long)N * NB;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sStage, &stg));
@@ -696,62 +1045,9 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     ND4_HIP(hipGetLastError());
     j_start = j0;
   }
-  // Two-level blocking for N > 2048 (round 3): with panels of 8 / 4 columns every step used to read-modify-write the whole trailing
-  // matrix (N^3 / (3 NB) * 16 B: 180 GB at 8192^2 for 366 GFLOP). Now an outer block of 256 columns (ND4HIP_LU_OUTER; 128: 4 % slower, 64: 10 %) is factorised by the same
-  // panel kernels with the rank-NB updates restricted to the block (the interchanges still go to every column at once: two rows per
-  // swap), then U12 = L11^-1 A12 for the whole block row (unit lower, the one-launch solver of trsm.hip on a contiguous
-  // copy) and ONE K = 256 product A22 -= L21 U12 on the tiled MFMA kernel. N <= 2048: one level (nbo = N), as before.
-  static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 256; }();
-  const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : N;
-  void* u12buf = nullptr;
-  if (NBO < N) ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NBO * N, &u12buf));
-  for (int J = j_start; J < N; J += NBO) {
-    const int bend = J + NBO < N ? J + NBO : N;               // end of the outer block
-    for (int j0 = J, step = NB; j0 < bend; j0 += step) {
-      const int m = N - j0;
-      // taller panels keep the thread-per-row layout on 1024 threads (128 VGPRs per lane) by narrowing the panel:
-      // 4 rows x 8 columns up to 4096 rows, 8 rows x 4 columns up to 8192 rows
-      const bool tall8 = m > 2048 && m <= 4096;
-      const bool tall4 = m > 4096 && m <= 8192;
-      step = tall8 ? 8 : tall4 ? 4 : NB;
-      const int nb = bend - j0 < step ? bend - j0 : step;
-      if (tall8) {
-        launch_panel_row_wt<4, 8, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      } else if (tall4) {
-        launch_panel_row_wt<8, 4, 1024>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      } else if (m >= 64 && m <= 2048) {
-        if (m <= 512)       launch_panel_row<1>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-        else if (m <= 1024) launch_panel_row<2>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-        else                launch_panel_row<4>(h, LU, N, strideM, j0, nb, P, ipiv, (int)batch, nopivot);
-      } else {
-        int T = ((m * NB + 63) / 64) * 64; if (T > 1024) T = 1024; if (T < 64) T = 64;
-        hipLaunchKernelGGL(lu_panel_global, dim3((unsigned)batch), dim3(T), 0, h->stream, LU, N, strideM, j0, nb, P, ipiv, nopivot);
-      }
-      const int rest = N - j0 - nb;
-      if (N > nb && (!nopivot || rest > 0))
-        hipLaunchKernelGGL(lu_laswp, dim3((unsigned)((N - nb + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
-                           LU, N, strideM, j0, nb, ipiv, nopivot ? 0 : 1, p_in_laswp ? P : (int32_t*)nullptr, bend);
-      const int inner = bend - j0 - nb;                        // columns of the block right of the panel
-      if (rest > 0 && inner > 0) {
-        ND4_HIP(hipGetLastError());
-        ND4_TRY(nd4_gemm(h, false, false, rest, inner, nb, -1.0,
-                         LU + (long)(j0 + nb) * N + j0, N, strideM,
-                         LU + (long)j0 * N + j0 + nb, N, strideM,
-                         1.0, LU + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
-      }
-    }
-    const int far = N - bend, nbo = bend - J;
-    if (far > 0 && NBO < N) {
-      ND4_HIP(hipGetLastError());
-      double* U12 = static_cast<double*>(u12buf);
-      const long sU = (long)nbo * far;
-      ND4_TRY(nd4_copy_matrix(h, nbo, far, LU + (long)J * N + bend, N, U12, far, batch, strideM, sU));
-      ND4_TRY(nd4_trsm_ld(h, false, true, batch, nbo, far, LU + (long)J * N + J, N, strideM, U12, sU));
-      ND4_TRY(nd4_copy_matrix(h, nbo, far, U12, far, LU + (long)J * N + bend, N, batch, sU, strideM));
-      ND4_TRY(nd4_gemm(h, false, false, far, far, nbo, -1.0, LU + (long)bend * N + J, N, strideM, U12, far, sU,
-                       1.0, LU + (long)bend * N + bend, N, strideM, batch));
-    }
-  }
+  // phase 3: what is left (short panels after the look-ahead form; everything when it is switched off), one level
+  if (j_start < N) ND4_TRY(outer_block(j_start, N, false));
+  if (mw_on && p_in_laswp) hipLaunchKernelGGL(lu_mw_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, stuck);
   if (p_in_laswp) { ND4_HIP(hipGetLastError()); return 0; }
   if ((size_t)N * sizeof(int32_t) <= 60 * 1024)
     hipLaunchKernelGGL(lu_build_perm, dim3((unsigned)batch), dim3(256), (size_t)N * sizeof(int32_t), h->stream, P, ipiv, N, nopivot);
