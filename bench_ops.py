@@ -250,12 +250,14 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
 def qr_panel(h, dev, M=2048, b=16, batch=256):
     """One panel factorisation kernel (Householder geqr2 + larft of b = 16 columns) on its own: a single 2048-row panel (one
     workgroup: a latency chain), 256 of them in one launch (one workgroup per matrix and per CU: the register tile of 4 rows x 16
-    columns per thread admits one workgroup per CU, so larger batches run at the same rate), and 2048 panels of 512 rows (1 row per
-    thread: three workgroups per CU)."""
+    columns per thread admits one workgroup per CU, so larger batches run at the same rate), and the throughput regime of shorter
+    panels, where the same kernel body runs on few waves with four rows per thread so that several workgroups share a CU: 2048
+    panels of 512 rows (128 threads each), 1024 of 1024 rows (256 threads), 4096 of 256 rows (one wave each)."""
     import ctypes
     from nd4js_amd import _lib
     res = {"cols": b, "algorithmic_bytes_per_panel_row": 16 * b}
-    for name, rows, nb in (("single", M, 1), ("batched", M, batch), ("batched_512rows", 512, 2048)):
+    for name, rows, nb in (("single", M, 1), ("batched", M, batch), ("batched_512rows", 512, 2048), ("batched_1024rows", 1024, 1024),
+                           ("batched_256rows", 256, 4096)):
         A = dev.fill_uniform(21, (nb, rows, b))
         V = torch.empty_like(A)
         T = torch.empty((nb, b, b), dtype=torch.float64, device="cuda")

@@ -256,6 +256,152 @@ __global__ __launch_bounds__(T) void lu_panel_row(double* __restrict__ LU, int N
   lu_panel_row_body<R, W, T>(blockIdx.x, LU, N, strideM, j0, nb, ipiv, nopivot);
 }
 
+// ---- look-ahead: everything panel pj0 does to ONE block of <= 16 columns outside it, by ONE workgroup ----
+// The 16 row interchanges, U12 = L11^-1 A12 and A22 -= L21 U12 are all local to a column, so one workgroup can take a block of columns
+// through all three without any other workgroup: the update of the columns BEHIND the next panel then runs in the same launch as the
+// next panel's factorisation (lu_panel_row_la: the panel keeps one workgroup busy for 20-37 us while the chip idled), and only the next
+// panel's own 16 columns are updated between two panels (lu_narrow_top + lu_narrow_gemm).
+// The interchanges are not replayed one after the other (a chain of 16 dependent load/store pairs): the rows they touch are the 16 top
+// rows and the <= 16 pivot rows, and what ends up in each of them is found by walking the transpositions backwards (16 compare steps
+// on registers), so it is one gather, a barrier, one scatter. right = false (columns left of the panel): the interchanges only.
+// Pm != nullptr: this workgroup also carries the permutation vector through the same gather (as one more column, lu.js:59-61).
+template <int NT, bool GEMM>
+__device__ __forceinline__ void lu_colblock_update(double* __restrict__ A, int N, int pj0, const int32_t* __restrict__ ip, int do_swap,
+                                                   int c0, int nc, bool right, int32_t* __restrict__ Pm) {
+  __shared__ int s_piv[NB], s_src[2 * NB], s_dst[2 * NB];
+  __shared__ double s_top[NB][NB + 1], s_l[NB][NB + 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  if (t < NB) s_piv[t] = do_swap ? ip[pj0 + t] : pj0 + t;
+  if (right && t >= 256 && t < 512) {                             // L11 (strictly lower, unit diagonal implied)
+    const int i = (t - 256) / NB, j = (t - 256) % NB;
+    s_l[i][j] = (j < i) ? A[(long)(pj0 + i) * N + pj0 + j] : 0.0;
+  }
+  __syncthreads();
+  if (t < 2 * NB) {
+    const int k = t & (NB - 1);
+    const int dst = t < NB ? pj0 + k : s_piv[k];
+    int pos = dst;
+#pragma unroll
+    for (int q = NB - 1; q >= 0; q--) {                           // where the content of row dst comes from: the transpositions backwards
+      const int ps = s_piv[q];
+      pos = (pos == pj0 + q) ? ps : ((pos == ps) ? pj0 + q : pos);
+    }
+    s_src[t] = pos;
+    s_dst[t] = (t < NB || dst >= pj0 + NB) ? dst : -1;             // a pivot row inside the top block is already there as a top row
+  }
+  __syncthreads();
+  double v[(2 * NB * NB + NT - 1) / NT];
+  int32_t pval = 0;
+#pragma unroll
+  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
+    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
+    v[e] = 0.0;
+    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) v[e] = A[(long)s_src[k] * N + c0 + c];
+  }
+  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) pval = Pm[s_src[t]];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
+    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
+    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) {
+      if (right && k < NB) s_top[k][c] = v[e];
+      else A[(long)s_dst[k] * N + c0 + c] = v[e];
+    }
+    if (idx < 2 * NB * NB && c >= nc && k < NB) s_top[k][c] = 0.0;
+  }
+  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) Pm[s_dst[t]] = pval;
+  if (!right) return;
+  __syncthreads();
+  if (t < NB) {                                                   // U12 = L11^-1 A12, one thread per column, same order as lu.js:71-72
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) x[i] = s_top[i][t];
+#pragma unroll
+    for (int i = 1; i < NB; i++) {
+      double acc = x[i];
+#pragma unroll
+      for (int j = 0; j < i; j++) acc -= s_l[i][j] * x[j];
+      x[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      s_top[i][t] = x[i];
+      if (t < nc) A[(long)(pj0 + i) * N + c0 + t] = x[i];
+    }
+  }
+  if constexpr (!GEMM) return;
+  __syncthreads();
+  // A22 -= L21 U12 on fp64 MFMA: the waves split the rows below the top block
+  constexpr int NW = NT / 64;
+  const int m2 = N - pj0 - NB;
+  const int rpw = ((m2 + NW * 16 - 1) / (NW * 16)) * 16;
+  const int r0 = wave * rpw, r1 = (r0 + rpw < m2) ? r0 + rpw : m2;
+  const bool cok = fx < nc;
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = -s_top[kk * 4 + fk][fx];
+  const double* Lp = A + (long)(pj0 + NB) * N + pj0;
+  double* Cp = A + (long)(pj0 + NB) * N + c0;
+  for (int rt = r0; rt < r1; rt += 64) {                          // four 16-row tiles per batch
+    double av[4][4]; d4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ra = rt + q * 16 + fx;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < r1) ? Lp[(long)ra * N + kk * 4 + fk] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        c[q][r] = (rc < r1 && cok) ? Cp[(long)rc * N + fx] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rt + q * 16 + fk + 4 * r;
+        if (rc < r1 && cok) Cp[(long)rc * N + fx] = c[q][r];
+      }
+    }
+  }
+}
+
+// which block of columns an update workgroup owns: block 0 = the permutation vector alone, then the blocks left of the panel at pj0
+// (interchanges only), then the blocks from column wide0 on
+// (two-level blocking: the blocks from column full_end on — beyond the outer block — get the interchanges only, like the left ones)
+template <int NT, bool GEMM>
+__device__ __forceinline__ void lu_update_block(int b, int mat, double* __restrict__ LU, int N, long strideM, int pj0, int wide0,
+                                                const int32_t* __restrict__ ipiv, int do_swap, int32_t* __restrict__ Pm, int full_end) {
+  double* A = LU + mat * strideM;
+  const int32_t* ip = ipiv + (long)mat * N;
+  const int nleft = pj0 / NB;
+  if (b == 0) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, 0, 0, false, Pm + (long)mat * N); return; }
+  b -= 1;
+  if (b < nleft) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, b * NB, NB, false, nullptr); return; }
+  const int c0 = wide0 + (b - nleft) * NB;
+  if (c0 >= full_end) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, c0, N - c0 < NB ? N - c0 : NB, false, nullptr); return; }
+  lu_colblock_update<NT, GEMM>(A, N, pj0, ip, do_swap, c0, N - c0 < NB ? N - c0 : NB, true, nullptr);
+}
+
+// panel at j0 (workgroup 0 of a matrix) together with everything the previous panel (at pj0) still owes the other columns
+template <int R>
+__global__ __launch_bounds__(512) void lu_panel_row_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ P,
+                                                        int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0,
+                                                        const double* __restrict__ stage, long strideStage, int full_end) {
+  if (blockIdx.x == 0) {
+    const double* sg = stage != nullptr ? stage + blockIdx.y * strideStage : nullptr;
+    lu_panel_row_body<R, NB, 512>(blockIdx.y, LU, N, strideM, j0, NB, ipiv, nopivot, sg != nullptr ? sg + NB * NB : nullptr, sg);
+    return;
+  }
+  lu_update_block<512, true>((int)blockIdx.x - 1, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P, full_end);
+}
+// the same update work on its own (the last look-ahead panel's debt)
+__global__ __launch_bounds__(512) void lu_update_blocks(double* __restrict__ LU, int N, long strideM, int32_t* __restrict__ P,
+                                                         const int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0, int full_end) {
+  lu_update_block<512, true>((int)blockIdx.x, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P, full_end);
+}
 // ---- panels taller than one workgroup's registers: the rows over P co-resident workgroups, ONE exchange per column (round 3) ----
 // Partial pivoting needs the arg-max over ALL rows below the diagonal for every column (lu.js:48-52), so a panel whose rows are
 // spread over workgroups needs one all-to-all per column. Done with fences (release: write back the L2, acquire: invalidate it) such
@@ -294,15 +440,18 @@ __device__ __forceinline__ double mw_ld(const mw_u64* slot, int v, unsigned tag,
   return __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
 }
 
+// stage != nullptr (look-ahead form): the panel's columns come from the contiguous block lu_narrow_fused has left behind, and the
+// 16 x 16 block of U above the panel (stage_top) is copied into place on the way (as in lu_panel_row_body).
 template <int R, int PQ, bool STAMPS = false>
-__global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ ipiv,
-                                                   int nopivot, double* __restrict__ xbuf, int* __restrict__ stuck, int P,
-                                                   unsigned long long* __restrict__ stamps = nullptr) {
+__device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, double* __restrict__ LU, int N, long strideM, int j0,
+                                                 int32_t* __restrict__ ipiv, int nopivot, double* __restrict__ xbuf, int* __restrict__ stuck,
+                                                 int P, unsigned long long* __restrict__ stamps, const double* __restrict__ stage,
+                                                 const double* __restrict__ stage_top) {
   constexpr int T = 512, W = NB, RT = R * T, NWV = 8;
+  const bool prio = stage_top != nullptr || stage != nullptr;
   __shared__ PivCand s_red[NWV];
   __shared__ double s_rows[NWV][W], s_j[W], s_u[W], s_dj[W];
   __shared__ int s_piv;
-  const int w = blockIdx.x, mat = blockIdx.y;
   double* A = LU + mat * strideM;
   int32_t* ip = ipiv + (long)mat * N;
   mw_u64* slots = reinterpret_cast<mw_u64*>(xbuf + mat * MW_STRIDE);
@@ -316,8 +465,8 @@ __global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int 
 #pragma unroll
     for (int c = 0; c < W; c++) a[i][c] = 0.0;
     if (r < N) {
-      const double* src = A + (long)r * N + j0;
-      if (vec) {
+      const double* src = stage != nullptr ? stage + (long)(r - j0) * W : A + (long)r * N + j0;
+      if (vec || stage != nullptr) {
 #pragma unroll
         for (int c = 0; c < W; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
       } else {
@@ -326,6 +475,8 @@ __global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int 
       }
     }
   }
+  if (stage_top != nullptr && w == 0 && t < NB * NB) A[(long)(j0 - NB + t / NB) * N + j0 + t % NB] = stage_top[t];   // U12 of the previous panel for these columns
+  if (prio) __builtin_amdgcn_s_setprio(3);          // the chain before the update workgroups that share the chip (and maybe the CU)
   auto column = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int jc = j0 + k, tag = jc + 1;
@@ -500,156 +651,32 @@ __global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int 
     }
   }
 }
+template <int R, int PQ, bool STAMPS = false>
+__global__ __launch_bounds__(512) void lu_panel_mw(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ ipiv,
+                                                   int nopivot, double* __restrict__ xbuf, int* __restrict__ stuck, int P,
+                                                   unsigned long long* __restrict__ stamps = nullptr) {
+  lu_panel_mw_body<R, PQ, STAMPS>(blockIdx.x, blockIdx.y, LU, N, strideM, j0, ipiv, nopivot, xbuf, stuck, P, stamps, nullptr, nullptr);
+}
+// the same panel (workgroups 0 .. P-1 of a matrix) together with everything the previous panel (at pj0) still owes the other columns
+template <int R, int PQ>
+__global__ __launch_bounds__(512) void lu_panel_mw_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ Pm,
+                                                      int32_t* __restrict__ ipiv, int nopivot, double* __restrict__ xbuf,
+                                                      int* __restrict__ stuck, int P, int pj0, int wide0,
+                                                      const double* __restrict__ stage, long strideStage, int full_end) {
+  if ((int)blockIdx.x < P) {
+    const double* sg = stage != nullptr ? stage + blockIdx.y * strideStage : nullptr;
+    lu_panel_mw_body<R, PQ, false>(blockIdx.x, blockIdx.y, LU, N, strideM, j0, ipiv, nopivot, xbuf, stuck, P, nullptr,
+                                   sg != nullptr ? sg + NB * NB : nullptr, sg);
+    return;
+  }
+  lu_update_block<512, true>((int)blockIdx.x - P, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, Pm, full_end);
+}
 __global__ void lu_mw_poison(int32_t* __restrict__ P, long total, const int* __restrict__ stuck) {
   if (*stuck == 0) return;
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i < total) P[i] = -1;
 }
 
-// ---- look-ahead: everything panel pj0 does to ONE block of <= 16 columns outside it, by ONE workgroup ----
-// The 16 row interchanges, U12 = L11^-1 A12 and A22 -= L21 U12 are all local to a column, so one workgroup can take a block of columns
-// through all three without any other workgroup: the update of the columns BEHIND the next panel then runs in the same launch as the
-// next panel's factorisation (lu_panel_row_la: the panel keeps one workgroup busy for 20-37 us while the chip idled), and only the next
-// panel's own 16 columns are updated between two panels (lu_narrow_top + lu_narrow_gemm).
-// The interchanges are not replayed one after the other (a chain of 16 dependent load/store pairs): the rows they touch are the 16 top
-// rows and the <= 16 pivot rows, and what ends up in each of them is found by walking the transpositions backwards (16 compare steps
-// on registers), so it is one gather, a barrier, one scatter. right = false (columns left of the panel): the interchanges only.
-// Pm != nullptr: this workgroup also carries the permutation vector through the same gather (as one more column, lu.js:59-61).
-template <int NT, bool GEMM>
-__device__ __forceinline__ void lu_colblock_update(double* __restrict__ A, int N, int pj0, const int32_t* __restrict__ ip, int do_swap,
-                                                   int c0, int nc, bool right, int32_t* __restrict__ Pm) {
-  __shared__ int s_piv[NB], s_src[2 * NB], s_dst[2 * NB];
-  __shared__ double s_top[NB][NB + 1], s_l[NB][NB + 1];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
-  if (t < NB) s_piv[t] = do_swap ? ip[pj0 + t] : pj0 + t;
-  if (right && t >= 256 && t < 512) {                             // L11 (strictly lower, unit diagonal implied)
-    const int i = (t - 256) / NB, j = (t - 256) % NB;
-    s_l[i][j] = (j < i) ? A[(long)(pj0 + i) * N + pj0 + j] : 0.0;
-  }
-  __syncthreads();
-  if (t < 2 * NB) {
-    const int k = t & (NB - 1);
-    const int dst = t < NB ? pj0 + k : s_piv[k];
-    int pos = dst;
-#pragma unroll
-    for (int q = NB - 1; q >= 0; q--) {                           // where the content of row dst comes from: the transpositions backwards
-      const int ps = s_piv[q];
-      pos = (pos == pj0 + q) ? ps : ((pos == ps) ? pj0 + q : pos);
-    }
-    s_src[t] = pos;
-    s_dst[t] = (t < NB || dst >= pj0 + NB) ? dst : -1;             // a pivot row inside the top block is already there as a top row
-  }
-  __syncthreads();
-  double v[(2 * NB * NB + NT - 1) / NT];
-  int32_t pval = 0;
-#pragma unroll
-  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
-    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
-    v[e] = 0.0;
-    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) v[e] = A[(long)s_src[k] * N + c0 + c];
-  }
-  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) pval = Pm[s_src[t]];
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < (2 * NB * NB + NT - 1) / NT; e++) {
-    const int idx = t + NT * e, k = idx / NB, c = idx % NB;
-    if (idx < 2 * NB * NB && c < nc && s_dst[k] >= 0) {
-      if (right && k < NB) s_top[k][c] = v[e];
-      else A[(long)s_dst[k] * N + c0 + c] = v[e];
-    }
-    if (idx < 2 * NB * NB && c >= nc && k < NB) s_top[k][c] = 0.0;
-  }
-  if (Pm != nullptr && t < 2 * NB && s_dst[t] >= 0) Pm[s_dst[t]] = pval;
-  if (!right) return;
-  __syncthreads();
-  if (t < NB) {                                                   // U12 = L11^-1 A12, one thread per column, same order as lu.js:71-72
-    double x[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) x[i] = s_top[i][t];
-#pragma unroll
-    for (int i = 1; i < NB; i++) {
-      double acc = x[i];
-#pragma unroll
-      for (int j = 0; j < i; j++) acc -= s_l[i][j] * x[j];
-      x[i] = acc;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      s_top[i][t] = x[i];
-      if (t < nc) A[(long)(pj0 + i) * N + c0 + t] = x[i];
-    }
-  }
-  if constexpr (!GEMM) return;
-  __syncthreads();
-  // A22 -= L21 U12 on fp64 MFMA: the waves split the rows below the top block
-  constexpr int NW = NT / 64;
-  const int m2 = N - pj0 - NB;
-  const int rpw = ((m2 + NW * 16 - 1) / (NW * 16)) * 16;
-  const int r0 = wave * rpw, r1 = (r0 + rpw < m2) ? r0 + rpw : m2;
-  const bool cok = fx < nc;
-  double bw[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; kk++) bw[kk] = -s_top[kk * 4 + fk][fx];
-  const double* Lp = A + (long)(pj0 + NB) * N + pj0;
-  double* Cp = A + (long)(pj0 + NB) * N + c0;
-  for (int rt = r0; rt < r1; rt += 64) {                          // four 16-row tiles per batch
-    double av[4][4]; d4 c[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int ra = rt + q * 16 + fx;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) av[q][kk] = (ra < r1) ? Lp[(long)ra * N + kk * 4 + fk] : 0.0;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rc = rt + q * 16 + fk + 4 * r;
-        c[q][r] = (rc < r1 && cok) ? Cp[(long)rc * N + fx] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c[q], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rc = rt + q * 16 + fk + 4 * r;
-        if (rc < r1 && cok) Cp[(long)rc * N + fx] = c[q][r];
-      }
-    }
-  }
-}
-
-// which block of columns an update workgroup owns: block 0 = the permutation vector alone, then the blocks left of the panel at pj0
-// (interchanges only), then the blocks from column wide0 on
-template <int NT, bool GEMM>
-__device__ __forceinline__ void lu_update_block(int b, int mat, double* __restrict__ LU, int N, long strideM, int pj0, int wide0,
-                                                const int32_t* __restrict__ ipiv, int do_swap, int32_t* __restrict__ Pm) {
-  double* A = LU + mat * strideM;
-  const int32_t* ip = ipiv + (long)mat * N;
-  const int nleft = pj0 / NB;
-  if (b == 0) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, 0, 0, false, Pm + (long)mat * N); return; }
-  b -= 1;
-  if (b < nleft) { if (do_swap) lu_colblock_update<NT, false>(A, N, pj0, ip, do_swap, b * NB, NB, false, nullptr); return; }
-  const int c0 = wide0 + (b - nleft) * NB;
-  lu_colblock_update<NT, GEMM>(A, N, pj0, ip, do_swap, c0, N - c0 < NB ? N - c0 : NB, true, nullptr);
-}
-
-// panel at j0 (workgroup 0 of a matrix) together with everything the previous panel (at pj0) still owes the other columns
-template <int R>
-__global__ __launch_bounds__(512) void lu_panel_row_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ P,
-                                                        int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0,
-                                                        const double* __restrict__ stage, long strideStage) {
-  if (blockIdx.x == 0) {
-    const double* sg = stage != nullptr ? stage + blockIdx.y * strideStage : nullptr;
-    lu_panel_row_body<R, NB, 512>(blockIdx.y, LU, N, strideM, j0, NB, ipiv, nopivot, sg != nullptr ? sg + NB * NB : nullptr, sg);
-    return;
-  }
-  lu_update_block<512, true>((int)blockIdx.x - 1, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P);
-}
-// the same update work on its own (the last look-ahead panel's debt)
-__global__ __launch_bounds__(512) void lu_update_blocks(double* __restrict__ LU, int N, long strideM, int32_t* __restrict__ P,
-                                                         const int32_t* __restrict__ ipiv, int nopivot, int pj0, int wide0) {
-  lu_update_block<512, true>((int)blockIdx.x, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, P);
-}
 // the next panel's own columns [c0, c0 + 16): interchanges + U12 by one workgroup, then the rank-16 update with the rows split over
 // workgroups of 256 (one workgroup is bound by the MFMA rate of its CU)
 __global__ __launch_bounds__(512) void lu_narrow_top(double* __restrict__ LU, int N, long strideM, const int32_t* __restrict__ ipiv,
@@ -906,16 +933,19 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   if (p_in_laswp) hipLaunchKernelGGL(lu_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, (int)N);
   int j_start = 0;
   // Two-level blocking for N > 2048 (round 3): with panels of 8 / 4 columns every step used to read-modify-write the whole trailing
-  // matrix (N^3 / (3 NB) * 16 B: 180 GB at 8192^2 for 366 GFLOP). Now an outer block of 256 columns (ND4HIP_LU_OUTER; 128: 4 % slower, 64: 10 %) is factorised by the same
+  // matrix (N^3 / (3 NB) * 16 B: 180 GB at 8192^2 for 366 GFLOP). Now an outer block of 512 columns (ND4HIP_LU_OUTER; with the look-ahead panels 256: 3 % slower, 1024: 1 % faster) is factorised by the same
   // panel kernels with the rank-NB updates restricted to the block (the interchanges still go to every column at once: two rows per
   // swap), then U12 = L11^-1 A12 for the whole block row (unit lower, the one-launch solver of trsm.hip on a contiguous
   // copy) and ONE K = 256 product A22 -= L21 U12 on the tiled MFMA kernel. N <= 2048: one level (nbo = N), as before.
-  static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 256; }();
+  static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 512; }();
   const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : N;
   void* u12buf = nullptr;
   if (NBO < N) ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NBO * N, &u12buf));
   // panels taller than 2048 rows: the rows over P co-resident workgroups of 512 threads x R rows (lu_panel_mw), 16 columns wide
-  static const int mw_r = [] { const char* e = getenv("ND4HIP_LU_MW_R"); return e ? atoi(e) : 4; }();   // 0: off (round 2's split panels)
+  // (rows per thread R: the fewest that keep P <= 16 — N <= 8192: 1, <= 16384: 2, <= 32768: 4; measured at 8192^2: 42.3 / 43.1 / 48.4 ms
+  //  for R = 1 / 2 / 4. ND4HIP_LU_MW_R = 1, 2, 4 forces one, 0 switches back to round 2's split panels.)
+  const int mw_env = [] { const char* e = getenv("ND4HIP_LU_MW_R"); return e ? atoi(e) : -1; }();   // (read per call: the tests switch it)
+  const int mw_r = mw_env >= 0 ? mw_env : (N <= MW_MAXP * 512 ? 1 : (N <= MW_MAXP * 1024 ? 2 : 4));
   const int mw_rt = (mw_r == 1 ? 1 : mw_r == 2 ? 2 : 4) * 512;
   const bool mw_on = mw_r != 0 && N > 2048 && (long)batch * ((N + mw_rt - 1) / mw_rt) <= 64 && N <= MW_MAXP * mw_rt;
   double* xbuf = nullptr; int* stuck = nullptr;
@@ -927,6 +957,21 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     stuck = static_cast<int*>(xb);
     xbuf = reinterpret_cast<double*>(static_cast<char*>(xb) + 256);
   }
+  // the part of an outer block's work beyond it: U12 = L11^-1 A12 for the whole block row, then ONE K = nbo product on the tiled MFMA kernel
+  auto outer_far = [&](const int J, const int bend) -> int {
+    const int far = N - bend, nbo = bend - J;
+    if (far > 0) {
+      ND4_HIP(hipGetLastError());
+      double* U12 = static_cast<double*>(u12buf);
+      const long sU = (long)nbo * far;
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, LU + (long)J * N + bend, N, U12, far, batch, strideM, sU));
+      ND4_TRY(nd4_trsm_ld(h, false, true, batch, nbo, far, LU + (long)J * N + J, N, strideM, U12, sU));
+      ND4_TRY(nd4_copy_matrix(h, nbo, far, U12, far, LU + (long)J * N + bend, N, batch, sU, strideM));
+      ND4_TRY(nd4_gemm(h, false, false, far, far, nbo, -1.0, LU + (long)bend * N + J, N, strideM, U12, far, sU,
+                       1.0, LU + (long)bend * N + bend, N, strideM, batch));
+    }
+    return 0;
+  };
   auto outer_block = [&](const int J, const int bend, const bool two_level) -> int {
     for (int j0 = J, step = NB; j0 < bend; j0 += step) {
       const int m = N - j0;
@@ -984,67 +1029,90 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
                          1.0, LU + (long)(j0 + nb) * N + j0 + nb, N, strideM, batch));
       }
     }
-    const int far = N - bend, nbo = bend - J;
-    if (far > 0 && two_level) {
-      ND4_HIP(hipGetLastError());
-      double* U12 = static_cast<double*>(u12buf);
-      const long sU = (long)nbo * far;
-      ND4_TRY(nd4_copy_matrix(h, nbo, far, LU + (long)J * N + bend, N, U12, far, batch, strideM, sU));
-      ND4_TRY(nd4_trsm_ld(h, false, true, batch, nbo, far, LU + (long)J * N + J, N, strideM, U12, sU));
-      ND4_TRY(nd4_copy_matrix(h, nbo, far, U12, far, LU + (long)J * N + bend, N, batch, sU, strideM));
-      ND4_TRY(nd4_gemm(h, false, false, far, far, nbo, -1.0, LU + (long)bend * N + J, N, strideM, U12, far, sU,
-                       1.0, LU + (long)bend * N + bend, N, strideM, batch));
-    }
+    if (two_level) ND4_TRY(outer_far(J, bend));
       return 0;
   };
-  // phase 1 (N > 2048): outer blocks while the panels are taller than 2048 rows
-  if (NBO < N) {
-    int J = 0;
-    for (; N - J > 2048; J += NBO) ND4_TRY(outer_block(J, J + NBO < N ? J + NBO : N, true));
-    j_start = J;
-  }
-  // ---- look-ahead form once the panels fit lu_panel_row<R, 16, 512> (the whole matrix for N <= 2048, the trailing <= 2048 rows of a
-  //      larger one): see lu_colblock_update ----
+  // ---- look-ahead form (see lu_colblock_update): the panel at j0 shares its launch with everything the previous panel still owes the
+  //      other columns; between two panels only the next panel's 16 columns are updated (staged out of place by lu_narrow_fused).
+  //      Panels of <= 2048 rows: lu_panel_row_la; taller ones (two-level blocking, the rows over P workgroups): lu_panel_mw_la.
+  //      [j_from, j_to): the panels of the range; full_end: columns from there on get the interchanges only (two-level: the outer
+  //      block's end; their U12 and update come from outer_far). Returns the first column it did not factorise. ----
   static const bool la_off = [] { const char* e = getenv("ND4HIP_LU_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
-  if (!la_off && N - j_start <= 2048 && N - j_start >= 64 + NB && p_in_laswp) {
-    int pj0 = -1;
-    int j0 = j_start;
+  static const bool fuse_off = [] { const char* e = getenv("ND4HIP_LU_NO_FUSED_NARROW"); return e && *e && *e != '0'; }();
+  const bool fused = !fuse_off && (N & 1) == 0;
+  const long sStage = (long)NB * NB + (long)N * NB;
+  double* stage = nullptr;
+  const bool la_on = !la_off && N >= 64 + NB && p_in_laswp;
+  if (la_on) {
     void* stg = nullptr;
-    const long sStage = (long)NB * NB + (long)N * NB;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sStage, &stg));
-    double* stage = static_cast<double*>(stg);
-    static const bool fuse_off = [] { const char* e = getenv("ND4HIP_LU_NO_FUSED_NARROW"); return e && *e && *e != '0'; }();
-    const bool fused = !fuse_off && (N & 1) == 0;
-    for (; N - j0 >= 64; j0 += NB) {
+    stage = static_cast<double*>(stg);
+  }
+  auto la_range = [&](const int j_from, const int j_to, const int full_end, int* j_next) -> int {
+    int pj0 = -1, j0 = j_from;
+    bool narrow_done = true;
+    for (; j0 < j_to && N - j0 >= 64; j0 += NB) {
       const int m = N - j0;
       // the panel at pj0 has reached its own columns and the 16 behind them (the narrow launch: [pj0 + NB, pj0 + 2 NB) = this panel,
       // staged out of place by lu_narrow_fused); it still owes the columns from pj0 + 2 NB on, the columns left of it, and P
       const int wide0 = pj0 + 2 * NB;
       const int nupd = pj0 < 0 ? 0 : 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
-      const dim3 grid((unsigned)(1 + nupd), (unsigned)batch);
       const double* sg = (fused && pj0 >= 0) ? stage : nullptr;
-      if (m <= 512)       hipLaunchKernelGGL(lu_panel_row_la<1>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
-      else if (m <= 1024) hipLaunchKernelGGL(lu_panel_row_la<2>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
-      else                hipLaunchKernelGGL(lu_panel_row_la<4>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pj0 < 0 ? 0 : pj0, wide0, sg, sStage);
+      const int pp = pj0 < 0 ? 0 : pj0;
+      if (m > 2048) {
+        const int Pw = (m + mw_rt - 1) / mw_rt;
+        const dim3 grid((unsigned)(Pw + nupd), (unsigned)batch);
+#define ND4_MWLA(RR, PQ) hipLaunchKernelGGL((lu_panel_mw_la<RR, PQ>), grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, xbuf, stuck, Pw, pp, wide0, sg, sStage, full_end)
+        if (mw_rt == 2048)      { if (Pw <= 4) ND4_MWLA(4, 1); else if (Pw <= 8) ND4_MWLA(4, 2); else ND4_MWLA(4, 4); }
+        else if (mw_rt == 1024) { if (Pw <= 4) ND4_MWLA(2, 1); else if (Pw <= 8) ND4_MWLA(2, 2); else ND4_MWLA(2, 4); }
+        else                    { if (Pw <= 4) ND4_MWLA(1, 1); else if (Pw <= 8) ND4_MWLA(1, 2); else ND4_MWLA(1, 4); }
+#undef ND4_MWLA
+      } else {
+        const dim3 grid((unsigned)(1 + nupd), (unsigned)batch);
+        if (m <= 512)       hipLaunchKernelGGL(lu_panel_row_la<1>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pp, wide0, sg, sStage, full_end);
+        else if (m <= 1024) hipLaunchKernelGGL(lu_panel_row_la<2>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pp, wide0, sg, sStage, full_end);
+        else                hipLaunchKernelGGL(lu_panel_row_la<4>, grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, pp, wide0, sg, sStage, full_end);
+      }
       const int c0 = j0 + NB;                                // the next panel's columns
-      const bool more = N - c0 >= 64;                        // another look-ahead panel follows: stage its columns out of place
+      const bool more = c0 < j_to && N - c0 >= 64;           // another look-ahead panel follows: stage its columns out of place
+      narrow_done = true;
       if (fused && more) {
         hipLaunchKernelGGL(lu_narrow_fused, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
                            LU, N, strideM, ipiv, nopivot, j0, stage, sStage);
-      } else {
+      } else if (c0 < full_end && c0 < N) {
         hipLaunchKernelGGL(lu_narrow_top, dim3((unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, ipiv, nopivot, j0, c0);
         hipLaunchKernelGGL(lu_narrow_gemm, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream, LU, N, strideM, j0, c0);
+      } else {
+        narrow_done = false;                                 // the range's last panel with nothing of the outer block right of it
       }
       pj0 = j0;
     }
-    {   // the last look-ahead panel's debt, then the remaining (short) panels the old way
-      const int wide0 = pj0 + 2 * NB;
+    if (pj0 >= 0) {   // the last panel's debt
+      const int wide0 = narrow_done ? pj0 + 2 * NB : pj0 + NB;
       const int nupd = 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
-      hipLaunchKernelGGL(lu_update_blocks, dim3((unsigned)nupd, (unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, P, ipiv, nopivot, pj0, wide0);
+      hipLaunchKernelGGL(lu_update_blocks, dim3((unsigned)nupd, (unsigned)batch), dim3(512), 0, h->stream, LU, N, strideM, P, ipiv, nopivot, pj0, wide0, full_end);
     }
     ND4_HIP(hipGetLastError());
-    j_start = j0;
+    *j_next = j0;
+    return 0;
+  };
+  // phase 1 (N > 2048): outer blocks while the panels are taller than 2048 rows
+  if (NBO < N) {
+    int J = 0;
+    for (; N - J > 2048; J += NBO) {
+      const int bend = J + NBO < N ? J + NBO : N;
+      if (la_on && mw_on && (bend - J) % NB == 0) {
+        int jn = 0;
+        ND4_TRY(la_range(J, bend, bend, &jn));
+        ND4_TRY(outer_far(J, bend));
+      } else {
+        ND4_TRY(outer_block(J, bend, true));
+      }
+    }
+    j_start = J;
   }
+  // phase 2: the look-ahead form on the whole matrix (N <= 2048) or on the trailing <= 2048 rows of a larger one
+  if (la_on && N - j_start <= 2048 && N - j_start >= 64 + NB) ND4_TRY(la_range(j_start, N, N, &j_start));
   // phase 3: what is left (short panels after the look-ahead form; everything when it is switched off), one level
   if (j_start < N) ND4_TRY(outer_block(j_start, N, false));
   if (mw_on && p_in_laswp) hipLaunchKernelGGL(lu_mw_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, stuck);

@@ -224,12 +224,13 @@ __global__ __launch_bounds__(1024) void qr_panel_flagged(double* __restrict__ Wm
 //                                       one column total per lane (+2 to finish the wave), 8 LDS partials per
 //                                       column, and the 16 totals come back as wave-uniform readlane values
 //   update a[r][c>k] -= tau v_r d[c];  a[r][k] = v_r;  z_k = d[c<k] feeds T.
-template <int R>
+template <int R, int NWV = 8>
 __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restrict__ Wm, int M, long ld, long strideW,
                                                   double* __restrict__ Vall, long ldv, long strideV,
                                                   double* __restrict__ Tall, long strideT,
                                                   double* __restrict__ taus, long strideTau, int j0, int nb) {
-  __shared__ double s_w[2][8][NB];        // per-wave column sums, double-buffered by column parity (one barrier per column)
+  constexpr int TT = 64 * NWV;               // threads of the workgroup: row of (thread t, slot i) = j0 + t + TT * i
+  __shared__ double s_w[2][NWV][NB];        // per-wave column sums, double-buffered by column parity (one barrier per column)
   __shared__ double s_top[2][NB];         // row jc of the tile as it stands before column k's reflector
   __shared__ double s_T[NB][NB + 1];
   __shared__ double s_Z[NB][NB];
@@ -243,7 +244,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
   double a[R][NB];
 #pragma unroll
   for (int i = 0; i < R; i++) {
-    const int r = j0 + t + 512 * i;
+    const int r = j0 + t + TT * i;
 #pragma unroll
     for (int c = 0; c < NB; c++) a[i][c] = 0.0;
     if (r < M) {
@@ -257,7 +258,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
       }
     }
   }
-  if (t < NB * (NB + 1)) (&s_T[0][0])[t] = 0.0;
+  for (int e = t; e < NB * (NB + 1); e += TT) (&s_T[0][0])[e] = 0.0;
 
   // one column step per compile-time k (generic lambda, see lu.hip: convergent DPP ops block `#pragma unroll`)
   auto column_step = [&](auto kc) __attribute__((always_inline)) {
@@ -272,7 +273,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
       for (int c = 0; c < NB; c++) d[c] = 0.0;
 #pragma unroll
       for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 512 * i;
+        const int r = j0 + t + TT * i;
         const double ak = (i > 0 || r > jc) ? a[i][k] : 0.0;           // row slots >= 1 are always below row jc
 #pragma unroll
         for (int c = 0; c < NB; c++) d[c] += ak * a[i][c];
@@ -296,7 +297,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
       __syncthreads();
       double tot = 0.0;                                   // lane -> column lane & 15
 #pragma unroll
-      for (int w = 0; w < 8; w++) tot += s_w[k & 1][w][lane & 15];
+      for (int w = 0; w < NWV; w++) tot += s_w[k & 1][w][lane & 15];
       double wv[NB];                                      // wave-uniform totals
 #define ND4_RL(C) wv[C] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), C), __builtin_amdgcn_readlane(__double2loint(tot), C));
       ND4_RL(0) ND4_RL(1) ND4_RL(2) ND4_RL(3) ND4_RL(4) ND4_RL(5) ND4_RL(6) ND4_RL(7)
@@ -318,7 +319,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
       double vr[R];
 #pragma unroll
       for (int i = 0; i < R; i++) {
-        const int r = j0 + t + 512 * i;
+        const int r = j0 + t + TT * i;
         vr[i] = (i > 0 || r > jc) ? a[i][k] * scale : ((r == jc) ? 1.0 : 0.0);
         const double tv = tau * vr[i];
 #pragma unroll
@@ -359,7 +360,7 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < R; i++) {
-    const int lr = t + 512 * i, r = j0 + lr;
+    const int lr = t + TT * i, r = j0 + lr;
     if (r < M) {
       double* w = A + (long)r * ld + j0;
       double* v = V + (long)r * ldv + j0;
@@ -381,18 +382,18 @@ __device__ __forceinline__ void qr_panel_row_body(const int mat, double* __restr
       }
     }
   }
-  if (t < NB * NB) {
-    const int i = t / NB, j = t % NB;
-    Tall[mat * strideT + (long)(j0 / NB) * NB * NB + t] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
+  for (int e = t; e < NB * NB; e += TT) {
+    const int i = e / NB, j = e % NB;
+    Tall[mat * strideT + (long)(j0 / NB) * NB * NB + e] = (i <= j && j < nb) ? s_T[i][j] : 0.0;
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(512) void qr_panel_row(double* __restrict__ Wm, int M, long ld, long strideW,
+template <int R, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void qr_panel_row(double* __restrict__ Wm, int M, long ld, long strideW,
                                                      double* __restrict__ Vall, long ldv, long strideV,
                                                      double* __restrict__ Tall, long strideT,
                                                      double* __restrict__ taus, long strideTau, int j0, int nb) {
-  qr_panel_row_body<R>(blockIdx.x, Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
+  qr_panel_row_body<R, NWV>(blockIdx.x, Wm, M, ld, strideW, Vall, ldv, strideV, Tall, strideT, taus, strideTau, j0, nb);
 }
 
 // ---- look-ahead: the block reflector applied to ONE block of <= 16 columns by ONE workgroup ----
@@ -1587,10 +1588,27 @@ __global__ __launch_bounds__(256) void qr_t_assemble(double* __restrict__ Tall, 
   Tall[so + t] = s_t[i][j];
 }
 
-template <int R>
+template <int R, int NWV = 8>
 void launch_panel_row(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
                       double* T, long sT, double* taus, long sTau, int j0, int nb) {
-  hipLaunchKernelGGL((qr_panel_row<R>), dim3(batch), dim3(512), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  hipLaunchKernelGGL((qr_panel_row<R, NWV>), dim3(batch), dim3(64 * NWV), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+}
+// The panel of m <= 2048 rows for `batch` matrices. One matrix is a latency problem: many waves with few rows each (R = 1, 2, 4 on
+// 512 threads). A batch that fills the chip is a throughput problem: the same body on FEW waves with four rows per thread
+// (128 threads for m <= 512, 256 for m <= 1024: 194 VGPRs, so four / two workgroups share a CU, their barriers cost next to nothing
+// and a column step is ~530 instructions of ONE wave) — 2048 panels of 512 rows: 220 -> 151 us, 4096 of 256 rows: 315 -> 154 us
+// (bench ops.qr_panel). All three shapes then run at the same 1.75 TB/s: the launch is bound by the instruction issue of the
+// 4096 wave-panels (8500 instructions each, two waves per SIMD); forcing three waves per SIMD spills (196 us).
+static void launch_panel_rows(nd4hip_handle* h, int batch, double* W, int M, int m, long ld, long sW, double* V, long ldv, long sV,
+                              double* T, long sT, double* taus, long sTau, int j0, int nb) {
+  static const int small_min = [] { const char* e = getenv("ND4HIP_QR_SMALL_WG_BATCH"); return e ? atoi(e) : 64; }();   // 0: never
+  const bool many = small_min > 0 && batch >= small_min;
+  if (many && m <= 256)       launch_panel_row<4, 1>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  else if (many && m <= 512)  launch_panel_row<4, 2>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  else if (many && m <= 1024) launch_panel_row<4, 4>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  else if (m <= 512)          launch_panel_row<1>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  else if (m <= 1024)         launch_panel_row<2>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
+  else                        launch_panel_row<4>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, nb);
 }
 // ---- exact power-of-two normalisation: the reference's Givens kernel (_giv_rot.js:22-37) scales by max(|a|,|b|)
 // and never overflows; Householder squares the entries. Per matrix: e = 0 if 2^-400 <= max|a| <= 2^400, else the
@@ -2058,9 +2076,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
         ND4_HIP(hipGetLastError());
       }
     } else
-    if (m <= 512)       launch_panel_row<1>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (m <= 1024) launch_panel_row<2>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else if (m <= 2048) launch_panel_row<4>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    if (m <= 2048)      launch_panel_rows(h, batch, W, M, m, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     ND4_HIP(hipGetLastError());
     // trailing columns of the outer block: C <- H^T C = (I - V T^T V^T) C
@@ -2146,9 +2162,7 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     ND4_TRY(hr.panel(0, NB, false, true));
     return 0;
   }
-  if (M <= 512)       launch_panel_row<1>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
-  else if (M <= 1024) launch_panel_row<2>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
-  else                launch_panel_row<4>(h, batch, A, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
+  launch_panel_rows(h, batch, A, M, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
   ND4_HIP(hipGetLastError());
   return 0;
 }
