@@ -643,7 +643,7 @@ constexpr double HR_PIVOT_THR = 1e-5;
 constexpr double HR_SERIES_MAX = 1e-5;
 constexpr int HR_MIN_ROWS = 64;
 
-enum { SEG_NX = 0, SEG_NA };
+enum { SEG_NX = 0, SEG_NA, SEG_NX0, SEG_F };   // SEG_NX0: partial X of the next panel's block alone; SEG_F: partial X, exchange, apply in one go
 struct QrhSeg { int kind, first, count; };
 
 struct QrhP {
@@ -666,6 +666,10 @@ struct QrhP {
                                     // a side workgroup takes TWO adjacent blocks (pairs of W blocks first, then pairs of Q^T blocks)
   int nseg; QrhSeg seg[2];          // the side work of this launch: workgroups nrow.. walk these segments
   int skip_x;                       // phase C: no partial X for the next panel (last panel of an outer block: the block update covers it)
+  int na_shift;                     // SEG_NA starts at this block of W (1: the fused launch B+C, whose row workgroups take the next panel's columns themselves)
+  unsigned long long* Xch; long strideXch;   // fused launch B+C: the row workgroups' exchange slots (512 tagged words each)
+  unsigned long long* Xsx; long strideXsx;   // fused side work: [column block][row chunk] slots of 512 tagged words (rcs_max chunks per block)
+  int rcs_max;
   long long* stamps; int stamp_slot; // debug (ND4HIP_QR_STAMPS): 100 MHz wall-clock stamps of workgroup 0, 8 per launch
 };
 
@@ -849,16 +853,46 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
   }
 }
 
+// ---- tagged words: the in-kernel exchange between co-resident workgroups (see qrh_bc) ----
+typedef unsigned long long qx_u64;
+constexpr int QX_SPIN_LIMIT = 1 << 20;
+__device__ __forceinline__ void qx_st(qx_u64* slot, int v, double x, unsigned tag) {
+  const qx_u64 bits = (qx_u64)__double_as_longlong(x), tg = (qx_u64)tag << 32;
+  __hip_atomic_store(slot + 2 * v, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot + 2 * v + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// fixed-order sum of entry v over the n slots (512 words apart); ok stays true only if every word carried the tag
+__device__ __forceinline__ double qx_sum(const qx_u64* __restrict__ slots, int v, int n, unsigned tag, bool& ok) {
+  double x = 0.0;
+  for (int p0 = 0; p0 < n; p0 += 8) {
+    qx_u64 w0[8], w1[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      const qx_u64* sp = slots + (long)(p0 + p < n ? p0 + p : 0) * 512 + 2 * v;
+      w0[p] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w1[p] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      if (p0 + p < n) {
+        ok = ok && (unsigned)(w0[p] >> 32) == tag && (unsigned)(w1[p] >> 32) == tag;
+        x += __longlong_as_double((long long)((w1[p] << 32) | (w0[p] & 0xffffffffull)));
+      }
+  }
+  return x;
+}
+
 // ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks (trailing columns of W, then
 // Q^T), in two phases split over 512-row chunks like the panel itself: partial X = V^T C (SEG_NX, launch A), C -= V (T^T X)
 // (SEG_NA: the blocks of W in launch B, whose first one phase C reads; those of Q^T in launch C) ----
 struct QrhSide { double* C; long ldc; int c0, nc, cb, rc; };   // cb: first block (index among W blocks, then Q^T blocks); nc: columns of the pair
 __device__ __forceinline__ QrhSide qrh_near_of(const QrhP& P, int mat, int e) {
   QrhSide s;
-  const int pr = e / P.nrc, nwp = (P.nnw + 1) / 2;
+  const int sh = P.na_shift;
+  const int pr = e / P.nrc, nwp = (P.nnw - sh + 1) / 2;
   s.rc = e % P.nrc;
   if (pr < nwp) {
-    s.cb = 2 * pr; s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB;
+    s.cb = sh + 2 * pr; s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0 + s.cb * NB;
     const int end = P.wide0 + P.nnw * NB < P.N ? P.wide0 + P.nnw * NB : P.N;
     s.nc = end - s.c0 < 2 * NB ? end - s.c0 : 2 * NB;
   } else {
@@ -907,6 +941,121 @@ __device__ __forceinline__ void qrh_near_apply(const QrhP& P, int mat, int e, do
                     P.Tall + mat * P.strideT + (long)(P.pj0 / NB) * NB * NB,
                     P.Vall + mat * P.strideV + P.pj0, P.ldv, s.C + s.c0, s.ldc, s.nc, P.pj0 + s.rc * 512 + wave * 64, P.M, c);
 }
+// ---- the two side phases of one (pair of column blocks, 512-row chunk) in ONE workgroup (round 3, second half) ----
+// Partial X = V^T C of the chunk, across to the nrc workgroups of the pair (consecutive workgroups of the launch: tagged words, see
+// qrh_bc), C -= V (T^T X) on the tiles that are still in the registers: the side blocks are read once and written once per
+// reflector instead of read twice and written once — the launches of the upper half of a 2048^2 factorisation are bound by exactly
+// this traffic. (The accumulator image c[q][r] of a 16-row tile and the slab image of its rows 4 (4q + r) + fk are the same registers.)
+__device__ __forceinline__ void qrh_side_fused(const QrhP& P, int mat, int e, double* __restrict__ s_buf) {
+  const QrhSide s = qrh_near_of(P, mat, e);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int vj0 = P.pj0, rb = vj0 + s.rc * 512 + wave * 64;
+  const double* V = P.Vall + mat * P.strideV + vj0;
+  const bool ok0 = fx < s.nc, ok1 = NB + fx < s.nc;
+  const unsigned tag = (unsigned)(vj0 / NB + 1);
+  double c0[16], c1[16];
+  d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0, y0 = x0, y1 = x0;
+  {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int r = rb + 4 * u + fk;
+      const bool rok = r < P.M;
+      const double* cp = s.C + (long)r * s.ldc + s.c0 + fx;
+      c0[u] = (rok && ok0) ? cp[0] : 0.0;
+      c1[u] = (rok && ok1) ? cp[NB] : 0.0;
+      v[u] = rok ? V[(long)r * P.ldv + fx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c0[u], x0, 0, 0, 0);
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], c1[u], y0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c0[u + 1], x1, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u + 1], c1[u + 1], y1, 0, 0, 0);
+    }
+  }
+  // the reflector rows as A operands of C -= V W (32 contiguous bytes per lane), requested before the exchange
+  double av[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = rb + q * 16 + fx;
+    if (ra < P.M) {
+      const double2 v0 = *reinterpret_cast<const double2*>(V + (long)ra * P.ldv + 4 * fk);
+      const double2 v1 = *reinterpret_cast<const double2*>(V + (long)ra * P.ldv + 4 * fk + 2);
+      av[q][0] = v0.x; av[q][1] = v0.y; av[q][2] = v1.x; av[q][3] = v1.y;
+    } else { av[q][0] = av[q][1] = av[q][2] = av[q][3] = 0.0; }
+  }
+  // fixed-order sums over the eight waves, then across: slot (block, chunk), entry = position in the 16 x 16 matrix
+  qx_u64* slots = P.Xsx + mat * P.strideXsx;
+  double* s_Tm = s_buf + 8 * 256;
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_buf[wave * 256 + (fk + 4 * r) * 16 + fx] = x0[r] + x1[r];
+  if (t < 256) s_Tm[t] = P.Tall[mat * P.strideT + (long)(vj0 / NB) * NB * NB + t];
+  __syncthreads();
+  if (t < 256) {
+    double xs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
+    qx_st(slots + ((long)s.cb * P.rcs_max + s.rc) * 512, t, xs, tag);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_buf[wave * 256 + (fk + 4 * r) * 16 + fx] = y0[r] + y1[r];
+  __syncthreads();
+  if (t >= 256 && s.nc > NB) {
+    double xs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + (t - 256)];
+    qx_st(slots + ((long)(s.cb + 1) * P.rcs_max + s.rc) * 512, t - 256, xs, tag);
+  }
+  __syncthreads();
+  double* s_X = s_buf;                                                 // 2 x 256
+  {
+    const int b = t >> 8, en = t & 255;
+    double x = 0.0;
+    if (b == 0 || s.nc > NB) {
+      const qx_u64* base = slots + (long)(s.cb + b) * P.rcs_max * 512;
+      int spins = 0;
+      for (;;) {
+        bool ok = true;
+        x = qx_sum(base, en, P.nrc, tag, ok);
+        if (ok || ++spins > QX_SPIN_LIMIT) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    s_X[t] = x;
+  }
+  __syncthreads();
+  double wv = 0.0;
+  {
+    const int b = t >> 8, i = (t & 255) / 16, j = t % 16;
+#pragma unroll
+    for (int l = 0; l < NB; l++) wv += s_Tm[l * 16 + i] * s_X[b * 256 + l * 16 + j];          // T^T X, T a full 16 x 16 matrix
+  }
+  __syncthreads();
+  s_X[t] = -wv;
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    const bool cok = b == 0 ? ok0 : ok1;
+    double bw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) bw[kk] = s_X[b * 256 + (4 * fk + kk) * 16 + fx];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      d4 c;
+#pragma unroll
+      for (int r = 0; r < 4; r++) c[r] = b == 0 ? c0[4 * q + r] : c1[4 * q + r];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][kk], bw[kk], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        if (rc < P.M && cok) s.C[(long)rc * s.ldc + s.c0 + b * NB + fx] = c[r];
+      }
+    }
+  }
+}
 // workgroup i of a launch's side work
 __device__ __forceinline__ void qrh_side(const QrhP& P, int mat, int i, double* __restrict__ s_buf) {
   int kind = -1, e = 0;
@@ -919,6 +1068,13 @@ __device__ __forceinline__ void qrh_side(const QrhP& P, int mat, int i, double* 
     qrh_side_x(P, mat, s, P.pj0, P.Xs + mat * P.strideXs + ((long)s.cb * P.nrc + s.rc) * 256, s_buf);
   } else if (kind == SEG_NA) {
     qrh_near_apply(P, mat, e, s_buf);
+  } else if (kind == SEG_NX0) {                                        // the block right behind the panel alone: e = row chunk
+    QrhSide s;
+    s.rc = e; s.cb = 0; s.C = P.Wm + mat * P.strideW; s.ldc = P.ld; s.c0 = P.wide0;
+    s.nc = P.N - s.c0 < NB ? P.N - s.c0 : NB;
+    qrh_side_x(P, mat, s, P.pj0, P.Xs + mat * P.strideXs + (long)s.rc * 256, s_buf);
+  } else if (kind == SEG_F) {
+    qrh_side_fused(P, mat, e, s_buf);
   }
 }
 // side work on its own (the flush after the last such panel)
@@ -930,6 +1086,24 @@ __global__ __launch_bounds__(512) void qrh_side_only(const QrhP P) {
 __device__ __forceinline__ void qrh_stamp(const QrhP& P, int k) {
   if (P.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.stamps[P.stamp_slot * 8 + k] = wall_clock64();
 }
+// X = V^T C over all m rows by the eight waves of one workgroup -> dst[256] (the fall-back panel's share of phase C)
+__device__ __forceinline__ void qrh_x_full(double* __restrict__ s_part, const double* __restrict__ V, long ldv, const double* __restrict__ C, long ldc,
+                                           int m, int nc, double* __restrict__ dst) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  const int rpw = ((m + 8 * 16 - 1) / (8 * 16)) * 16;
+  const int r0 = wave * rpw, r1 = (r0 + rpw < m) ? r0 + rpw : m;
+  const bool cok = fx < nc;
+  d4 a0 = d4{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+  for (int rr = r0; rr < r1; rr += 8) {
+    const int ra = rr + fk, rb2 = rr + 4 + fk;
+    const double va = ra < r1 ? V[(long)ra * ldv + fx] : 0.0, ca = (ra < r1 && cok) ? C[(long)ra * ldc + fx] : 0.0;
+    const double vb = rb2 < r1 ? V[(long)rb2 * ldv + fx] : 0.0, cb = (rb2 < r1 && cok) ? C[(long)rb2 * ldc + fx] : 0.0;
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va, ca, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb, cb, a1, 0, 0, 0);
+  }
+  qrh_reduce_store(s_part, a0, a1, dst);
+}
+
 // ---- phase A: the previous reflector on the panel's own columns (rows from j0 - 16), then the partial Gram matrices ----
 __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
   __shared__ double s_buf[QRH_SMEM];
@@ -943,7 +1117,17 @@ __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
   d4 (&c)[4] = cc[0];
   qrh_stamp(P, 0);
   if (P.pj0 >= 0) {
-    qrh_apply_rows<1>(s_buf, P.Xp + mat * P.strideXp, 0, P.nxp, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+    const double* Xsrc = P.Xp + mat * P.strideXp;
+    int nx = P.nxp;
+    if (P.Xch != nullptr && P.flag[mat]) {
+      // the previous panel took the fall-back inside the fused launch B+C, which leaves no partials of X behind: every workgroup
+      // forms X = V^T C over all rows itself (rare path), in its own slot of Xp
+      double* mine = P.Xp + mat * P.strideXp + (long)g * 256;
+      qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)ub * P.ldv + ub, P.ldv, A + (long)ub * P.ld + j0, P.ld, M - ub, NB, mine);
+      __syncthreads();
+      Xsrc = mine; nx = 1;
+    }
+    qrh_apply_rows<1>(s_buf, Xsrc, 0, nx, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
                       P.Vall + mat * P.strideV + ub, P.ldv, A + j0, P.ld, NB, rb, M, cc);
     __syncthreads();                                                  // s_buf is reused below
     qrh_stamp(P, 1);
@@ -981,14 +1165,14 @@ __global__ __launch_bounds__(512) void qrh_gram(const QrhP P) {
 }
 
 // the wave's 64 rows of the panel's 16 columns as MFMA A operands (k-step kk <-> column 4 fk + kk: 32 contiguous bytes per lane)
-__device__ __forceinline__ void qrh_load_rows(const double* __restrict__ A, long ld, int j0, int rb, int M, double (&a)[4][4]) {
+__device__ __forceinline__ void qrh_load_rows(const double* __restrict__ A, long ld, int j0, int rb, int M, double (&a)[4][4], int lo = 0) {
   const int lane = threadIdx.x & 63, fx = lane & 15, fk = lane >> 4;
   const bool vec = (ld & 1) == 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int ra = rb + q * 16 + fx;
     const double* src = A + (long)ra * ld + j0 + 4 * fk;
-    if (ra < M) {
+    if (ra < M && ra >= lo) {
       if (vec) {
         const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
         a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
@@ -1060,24 +1244,6 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
   }
   qrh_reduce_store(s_buf, g0, g1, P.G2p + mat * P.strideG2 + (long)g * 256);
   qrh_stamp(P, 4);
-}
-
-// X = V^T C over all m rows by the eight waves of one workgroup -> dst[256] (the fall-back panel's share of phase C)
-__device__ __forceinline__ void qrh_x_full(double* __restrict__ s_part, const double* __restrict__ V, long ldv, const double* __restrict__ C, long ldc,
-                                           int m, int nc, double* __restrict__ dst) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
-  const int rpw = ((m + 8 * 16 - 1) / (8 * 16)) * 16;
-  const int r0 = wave * rpw, r1 = (r0 + rpw < m) ? r0 + rpw : m;
-  const bool cok = fx < nc;
-  d4 a0 = d4{0.0, 0.0, 0.0, 0.0}, a1 = a0;
-  for (int rr = r0; rr < r1; rr += 8) {
-    const int ra = rr + fk, rb2 = rr + 4 + fk;
-    const double va = ra < r1 ? V[(long)ra * ldv + fx] : 0.0, ca = (ra < r1 && cok) ? C[(long)ra * ldc + fx] : 0.0;
-    const double vb = rb2 < r1 ? V[(long)rb2 * ldv + fx] : 0.0, cb = (rb2 < r1 && cok) ? C[(long)rb2 * ldc + fx] : 0.0;
-    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va, ca, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb, cb, a1, 0, 0, 0);
-  }
-  qrh_reduce_store(s_part, a0, a1, dst);
 }
 
 // ---- phase C: R2, the representation (W, K, S R), and the partials of X = V^T C for the next panel's columns ----
@@ -1229,6 +1395,243 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   }
   qrh_stamp(P, 5);
   qrh_stamp(P, 6);
+}
+
+// ---- phases B and C in ONE launch (round 3, second half) ----
+// What phase C needs from the other row workgroups of phase B is one 16 x 16 matrix each (the partial Gram matrix of Q1). An exchange
+// of that size inside a kernel costs ~1.4 us on this chip when it is made of agent-scope relaxed atomics only (sc1 stores are
+// written through, sc1 loads miss the non-coherent caches: no write-back, no invalidate; tools/xwg_lat.hip, lu.hip: lu_panel_mw) —
+// less than the kernel boundary it replaces, and the panel's rows need not be read a third time: Q1 stays in the registers (its
+// accumulator image goes through LDS once to become the A operand of Q = Q1 R2^-1). Every 8-byte word that crosses carries 32 bits
+// of payload and a 32-bit tag (panel number + 1): a double is valid as soon as both its words carry the tag, so there is no flag,
+// no s_waitcnt and no ordering between words. The row partition is phase A's (rows from j0 - 16: tile 0 of workgroup 0 lies above
+// the panel and only sees the previous reflector). The next panel's 16 columns get the previous reflector from the ROW workgroups
+// here (X summed from the side partials of launch A), each for its own rows, which it then holds for the partial X of the next
+// panel: the side work of this launch starts one block later (na_shift) and covers W and Q^T in one go.
+// A flagged panel: workgroup 0 runs qr_panel_row_body (R > 0; tall panels: qr_panel_flagged in a launch of its own, as before) and
+// nobody writes partials of X: the next launch A forms X itself (qrh_gram), the last panel's narrow update goes through qrh_x_flagged.
+template <int R>
+__global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
+  __shared__ double s_buf[QRH_SMEM];
+  __shared__ double s_G[256], s_R[256], s_Ri[256], s_db[16];
+  __shared__ int s_flag, s_emax;
+  const int mat = blockIdx.y;
+  if ((int)blockIdx.x >= P.nrow) { qrh_side(P, mat, (int)blockIdx.x - P.nrow, s_buf); return; }
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, fx = lane & 15, fk = lane >> 4;
+  double* A = P.Wm + mat * P.strideW;
+  const int j0 = P.j0, M = P.M, N = P.N, ub = j0 - NB;
+  const long ld = P.ld;
+  const int c0 = j0 + NB, nc = P.skip_x ? 0 : (N - c0 < NB ? N - c0 : NB);   // the next panel's columns (nc <= 0: none)
+  const int rb = ub + (g * 8 + wave) * 64;                                  // phase A's row partition
+  const unsigned tag = (unsigned)(j0 / NB + 1);
+  qx_u64* slots = P.Xch + mat * P.strideXch;
+  double* Xdst = P.Xp + mat * P.strideXp + (long)g * 256;
+  qrh_stamp(P, 0);
+  // ---- the next panel's columns: the previous reflector for this workgroup's rows (kept in cs for the partial X below) ----
+  d4 csb[1][4];
+  d4 (&cs)[4] = csb[0];
+  if (nc > 0 && P.pj0 >= 0) {
+    qrh_apply_rows<1>(s_buf, P.Xs + mat * P.strideXs, 0, P.nrc, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                      P.Vall + mat * P.strideV + ub, P.ldv, A + c0, ld, nc, rb, M, csb);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        cs[q][r] = (rc >= j0 && rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
+      }
+    }
+  }
+  // ---- phase B: R1 = chol(G), the fall-back decision ----
+  double a[4][4];
+  qrh_load_rows(A, ld, j0, rb, M, a, j0);
+  if (t < 256) {
+    const double gb = qrh_sum_parts(P.Gp + mat * P.strideGp + 256 + t, P.ngp);
+    s_G[t] = gb + P.Gp[mat * P.strideGp + t];
+    if (t % 17 == 0) s_db[t / 17] = gb;                               // column sums of squares below the top block
+  }
+  if (t == 0) s_emax = 0;
+  __syncthreads();
+  qrh_stamp(P, 1);
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) ok = ok && (s_db[k] > 0.0);
+    if (lane == 0) s_flag = ok ? 0 : 1;
+  }
+  __syncthreads();
+  const int flag = s_flag;                                            // (the same in every row workgroup: same sums in the same order)
+  qrh_stamp(P, 2);
+  if (g == 0 && t == 0) P.flag[mat] = flag;
+  if (flag) {
+    if constexpr (R > 0) {
+      if (g == 0) qr_panel_row_body<(R > 0 ? R : 1)>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
+    }
+    return;
+  }
+  // ---- Q1 = C R1^-1 (registers), its partial Gram matrix across to the other row workgroups ----
+  double bw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_Ri[(4 * fk + kk) * 16 + fx];
+  d4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], bw[kk], acc[q], 0, 0, 0);
+  }
+  d4 g0 = d4{0.0, 0.0, 0.0, 0.0}, g1 = g0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][0], acc[q][0], g0, 0, 0, 0);
+    g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][1], acc[q][1], g1, 0, 0, 0);
+    g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][2], acc[q][2], g0, 0, 0, 0);
+    g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q][3], acc[q][3], g1, 0, 0, 0);
+  }
+  double* s_E = s_buf + QRH_LDS; double* s_F = s_E + 256; double* s_P = s_F + 256; double* s_Qt = s_P + 512;
+  double* s_R2 = s_Qt + 256; double* s_R2i = s_R2 + 256; double* s_Z = s_R2i + 256; double* s_Rm = s_Z + 256; double* s_K = s_Rm + 256; double* s_S = s_K + 256;
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_buf[wave * 256 + (fk + 4 * r) * 16 + fx] = g0[r] + g1[r];
+  if (g == 0 && wave == 0) {                                           // top block of Q1 (tile 1)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s_Qt[(fk + 4 * r) * 16 + fx] = acc[1][r];
+  }
+  __syncthreads();
+  const int i = (t & 255) / 16, j = t % 16;
+  if (t < 256) {
+    double xs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
+    qx_st(slots + (long)g * 512, t, xs, tag);
+  }
+  qrh_stamp(P, 3);
+  double x = 0.0;
+  if (t < 256) {
+    int spins = 0;
+    for (;;) {
+      bool ok = true;
+      x = qx_sum(slots, t, P.nrow, tag, ok);
+      if (ok || ++spins > QX_SPIN_LIMIT) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    x -= (i == j) ? 1.0 : 0.0;                                         // E = Q1^T Q1 - I
+    s_E[t] = x;
+    s_F[t] = (i < j) ? x : ((i == j) ? 0.5 * x : 0.0);
+    const float ax = fabsf((float)x);
+    atomicMax(&s_emax, (ax == ax) ? __float_as_int(ax) : 0x7f800000);
+  }
+  __syncthreads();
+  const bool series = __int_as_float(s_emax) <= (float)HR_SERIES_MAX;
+  qrh_stamp(P, 4);
+  // Q1 from its accumulator image to the A-operand image, one tile at a time through the wave's own piece of LDS (rows padded to 17
+  // doubles; the DS operations of one wave execute in order, the waits keep compiler and hardware from overlapping write and read;
+  // the eight partial matrices that lay there were consumed before the barrier above)
+  {
+    double* sw = s_buf + wave * 272;                                   // 8 x 272 doubles: fits in front of QRH_LDS
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) sw[(fk + 4 * r) * 17 + fx] = acc[q][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) a[q][kk] = sw[fx * 17 + 4 * fk + kk];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (series) {
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += s_F[l * 16 + i] * s_F[l * 16 + j];
+      s_P[t] = pp;
+    }
+    __syncthreads();
+    if (t < 256) {
+      const double xx = s_E[t] - s_P[t];
+      s_F[t] = (i < j) ? xx : ((i == j) ? 0.5 * xx : 0.0);
+    }
+    __syncthreads();
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += s_F[i * 16 + l] * s_F[l * 16 + j];
+      s_P[t] = pp + ((i == j) ? 1.0 : 0.0);                            // I + F^2
+      s_R2[t] = s_F[t] + ((i == j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (t < 256) {
+      double pp = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) pp += (((i == l) ? 1.0 : 0.0) - s_F[i * 16 + l]) * s_P[l * 16 + j];
+      s_R2i[t] = pp;
+    }
+  } else {
+    if (t < 256) s_E[t] += (i == j) ? 1.0 : 0.0;
+    __syncthreads();
+    if (wave == 0) (void)qrh_chol16(s_E, s_R2, s_R2i, 0.0);
+  }
+  __syncthreads();
+  if (g == 0) {                                                        // only workgroup 0 holds the top block: Z, R, K, S
+    if (t < 256) {
+      double z = 0.0, rr = 0.0;
+#pragma unroll
+      for (int l = 0; l < 16; l++) {
+        z += s_Qt[i * 16 + l] * s_R2i[l * 16 + j];                     // top block of Q = Q1 R2^-1
+        rr += s_R2[i * 16 + l] * s_R[l * 16 + j];                      // R = R2 R1
+      }
+      s_Z[t] = z; s_Rm[t] = rr;
+    }
+    __syncthreads();
+    qrh_stamp(P, 5);
+    if (wave == 0) { __builtin_amdgcn_s_setprio(3); qrh_gj16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
+  d4 y[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    y[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) y[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], bw[kk], y[q], 0, 0, 0);
+  }
+  if (g == 0) __syncthreads();                                         // s_K, s_S (uniform per workgroup)
+  qrh_stamp(P, 6);
+  double* V = P.Vall + mat * P.strideV + j0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const bool top = (g == 0 && wave == 0 && q == 1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int ii = fk + 4 * r, rc = rb + q * 16 + ii;
+      double wv = 0.0;
+      if (top) {                                                       // W = Q - [S; 0]; R = S R2 R1 in place
+        if (ii == fx) y[q][r] -= s_S[ii];
+        wv = (ii <= fx) ? s_S[ii] * s_Rm[ii * 16 + fx] : 0.0;
+      }
+      if (rc >= j0 && rc < M) { V[(long)rc * P.ldv + fx] = y[q][r]; A[(long)rc * ld + j0 + fx] = wv; }
+    }
+  }
+  if (g == 0) {
+    if (t < 256) P.Tall[mat * P.strideT + (long)(j0 / NB) * NB * NB + t] = s_K[t];
+    if (t < 16) P.taus[mat * P.strideTau + j0 + t] = 1.0;             // "a reflector was needed" (qr_flips)
+  }
+  if (nc > 0) {
+    d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = x0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][0], cs[q][0], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][1], cs[q][1], x1, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][2], cs[q][2], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q][3], cs[q][3], x1, 0, 0, 0);
+    }
+    __syncthreads();                                                   // (the relayout pieces in s_buf are consumed)
+    qrh_reduce_store(s_buf, x0, x1, Xdst);
+  }
+  qrh_stamp(P, 7);
 }
 
 // partials of X = V^T C for the next panel's columns after qr_panel_flagged (workgroup 0: all rows; the others: zero)
@@ -1683,6 +2086,7 @@ struct QrhHost {
   nd4hip_handle* h; QrhP P; int batch; int nq;          // nq: column blocks of Q^T (0: no Q^T accumulation)
   double *V, *T; long ldv, sV, sT;                        // for qr_narrow_apply
   int pj0 = -1;                                           // the reflector whose narrow / side work is pending (-1: none)
+  bool fused_last = false;                                // the last panel went through qrh_bc
   void add_seg(int kind, int first, int count) { if (count > 0) { P.seg[P.nseg].kind = kind; P.seg[P.nseg].first = first; P.seg[P.nseg].count = count; P.nseg++; } }
   int seg_total() const { int n = 0; for (int i = 0; i < P.nseg; i++) n += P.seg[i].count; return n; }
   void side_launch() { if (P.nseg > 0) hipLaunchKernelGGL(qrh_side_only, dim3((unsigned)seg_total(), (unsigned)batch), dim3(512), 0, h->stream, P); P.nseg = 0; }
@@ -1700,10 +2104,45 @@ struct QrhHost {
     const int m = P.M - j0;
     int side_w = 0, side_all = 0;
     side_of(pj0, near_end, with_qt, side_w, side_all);
-    P.j0 = j0; P.pj0 = pj0; P.skip_x = skip_x ? 1 : 0;
+    P.j0 = j0; P.pj0 = pj0; P.skip_x = skip_x ? 1 : 0; P.na_shift = 0;
     const int nA = (m + NB + 511) / 512, nB = (m + 511) / 512;
+    // phases B and C in one launch (qrh_bc): the row workgroups keep phase A's partition and exchange the Gram matrices of Q1 inside
+    // the kernel; they also take the next panel's columns through the previous reflector, so the side work starts one block later.
+    // The side work itself: both phases of a (block pair, row chunk) in one workgroup (qrh_side_fused): W pairs ride in launch A,
+    // Q^T pairs in launch B+C; only the next panel's own block still needs its partial X ahead of launch B+C (SEG_NX0).
+    static const bool bc_off = [] { const char* e = getenv("ND4HIP_QR_NO_FUSED_BC"); return e && *e && *e != '0'; }();
+    static const bool sf_off = [] { const char* e = getenv("ND4HIP_QR_NO_FUSED_SIDE"); return e && *e && *e != '0'; }();
+    const bool next_cols = !skip_x && j0 + NB < P.N;
+    if (!bc_off && P.Xch != nullptr && !(pj0 >= 0 && next_cols && P.nnw < 1)) {
+      const int sh = (pj0 >= 0 && next_cols) ? 1 : 0;
+      const int nwp = pj0 >= 0 ? (P.nnw - sh + 1) / 2 : 0, nqp = pj0 >= 0 ? (P.nqb + 1) / 2 : 0;
+      const bool sf = !sf_off && P.Xsx != nullptr;
+      P.nrow = nA; P.ngp = 0; P.nseg = 0;
+      static const int sf_a = [] { const char* e = getenv("ND4HIP_QR_SIDE_IN_A"); return e ? atoi(e) : 0; }();   // percent of the W pairs that ride in launch A
+      const int nwa = nwp * sf_a / 100;
+      if (sf) { P.na_shift = sh; if (sh) add_seg(SEG_NX0, 0, P.nrc); add_seg(SEG_F, 0, nwa * P.nrc); }
+      else add_seg(SEG_NX, 0, side_all);
+      hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+      P.na_shift = sh;
+      P.nrow = nA; P.ngp = nA; P.nseg = 0;
+      if (sf) add_seg(SEG_F, nwa * P.nrc, (nwp - nwa + nqp) * P.nrc); else add_seg(SEG_NA, 0, (nwp + nqp) * P.nrc);
+      const dim3 gc((unsigned)(nA + seg_total()), (unsigned)batch);
+      if (m <= 512)       hipLaunchKernelGGL(qrh_bc<1>, gc, dim3(512), 0, h->stream, P);
+      else if (m <= 1024) hipLaunchKernelGGL(qrh_bc<2>, gc, dim3(512), 0, h->stream, P);
+      else if (m <= 2048) hipLaunchKernelGGL(qrh_bc<4>, gc, dim3(512), 0, h->stream, P);
+      else {
+        hipLaunchKernelGGL(qrh_bc<0>, gc, dim3(512), 0, h->stream, P);
+        hipLaunchKernelGGL(qr_panel_flagged, dim3((unsigned)batch), dim3(1024), 0, h->stream, P.Wm, P.M, P.ld, P.strideW, P.Vall, P.ldv, P.strideV,
+                           P.Tall, P.strideT, P.taus, P.strideTau, j0, NB, P.flag);
+      }
+      P.na_shift = 0;
+      pj0 = j0; P.nxp = nA; P.nseg = 0; P.stamp_slot++; fused_last = true;
+      ND4_HIP(hipGetLastError());
+      return 0;
+    }
     P.nrow = nA; P.ngp = 0; P.nseg = 0; add_seg(SEG_NX, 0, side_all);
     hipLaunchKernelGGL(qrh_gram, dim3((unsigned)(nA + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
+    fused_last = false;
     P.nrow = nB; P.ngp = nA; P.nseg = 0; add_seg(SEG_NA, 0, side_w);
     hipLaunchKernelGGL(qrh_chol, dim3((unsigned)(nB + seg_total()), (unsigned)batch), dim3(512), 0, h->stream, P); P.stamp_slot++;
     P.ngp = nB; P.nseg = 0; add_seg(SEG_NA, side_w, side_all - side_w);
@@ -1727,6 +2166,10 @@ struct QrhHost {
     if (pj0 < 0) return 0;
     if (narrow && pj0 + NB < P.N) {
       const int m = P.M - pj0;
+      if (fused_last) {   // a flagged panel of the fused launch left no partials of X behind
+        P.j0 = pj0; P.na_shift = 0;
+        hipLaunchKernelGGL(qrh_x_flagged, dim3((unsigned)P.nxp, (unsigned)batch), dim3(512), 0, h->stream, P);
+      }
       hipLaunchKernelGGL(qr_narrow_apply, dim3((unsigned)((m + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
                          P.Wm, P.M, P.N, P.ld, P.strideW, V, ldv, sV, T, sT, pj0, pj0 + NB, P.Xp, P.strideXp, P.nxp);
     }
@@ -1746,7 +2189,7 @@ struct QrhHost {
     ND4_HIP(hipMemcpy(st.data(), P.stamps, sizeof(long long) * st.size(), hipMemcpyDeviceToHost));
     (void)hipFree(P.stamps); P.stamps = nullptr;
     for (int i = 0; i < P.stamp_slot; i++) {
-      fprintf(stderr, "qrh stamp launch %d (%c panel %d):", i, "ABC"[i % 3], i / 3);
+      fprintf(stderr, "qrh stamp launch %d:", i);
       for (int k = 0; k < 8; k++) fprintf(stderr, " %.2f", st[i * 8 + k] ? (st[i * 8 + k] - st[0]) * 0.01 : 0.0);
       fprintf(stderr, "\n");
     }
@@ -1839,10 +2282,11 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   const bool hr_tall = !hr_off && !la_off && batch <= 8 && M > 2048 && M <= 16384 && L >= 256 && (L % NB == 0 || M - (L / NB) * NB <= 2048);
   const bool use_hr = (lookahead && !hr_off && batch <= 8) || hr_tall;    // multi-workgroup panels (CholeskyQR2 + compact orthogonal completion)
   const int hr_parts = (M + NB + 511) / 512 + 1;
-  const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 256 : 0, sR1 = use_hr ? 256 : 0;
+  const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 512 : 0, sR1 = use_hr ? 256 : 0;   // G2: partials (3 launches) or 512 tagged words per row workgroup (qrh_bc)
   const long hr_rcs = (M + 511) / 512;
   const long sXs = use_hr ? ((N + NB - 1) / NB + (use_qt ? (M + NB - 1) / NB : 0)) * hr_rcs * 256 : 0;   // side work: [column block][row chunk][256]
-  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT + sGp + sG2 + sR1 + sXs);
+  const long sXsx = 2 * sXs;                                 // fused side work: 512 tagged words per (column block, row chunk)
+  size_t doubles = (size_t)batch * (ws.sV + 2 * ws.sT + ws.sTau + ws.sWb + ws.sW2 + sWork + sQT + sGp + sG2 + sR1 + sXs + sXsx);
   size_t bytes = doubles * sizeof(double) + ((size_t)batch * L + 2) * sizeof(int) + (size_t)batch * 8 + (size_t)batch * sizeof(int) + 64;
   void* p = nullptr;
   Nd4WsScope scope(h);
@@ -1860,6 +2304,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   double* hrG2 = d; d += (size_t)batch * sG2;
   double* hrR1 = d; d += (size_t)batch * sR1;
   double* hrXs = d; d += (size_t)batch * sXs;
+  double* hrXsx = d; d += (size_t)batch * sXsx;
   ws.flips = reinterpret_cast<int*>(d);
 
   // working matrix: R's buffer when it has A's shape (M <= N), a workspace copy when tall
@@ -1887,6 +2332,11 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     P.Wm = W; P.M = M; P.N = N; P.ld = ld; P.strideW = sW; P.Vall = ws.V; P.ldv = ws.ldv; P.strideV = ws.sV; P.Tall = ws.T; P.strideT = ws.sT;
     P.taus = ws.taus; P.strideTau = ws.sTau; P.Xp = ws.Wp; P.strideXp = ws.sWb; P.Gp = hrGp; P.strideGp = sGp; P.G2p = hrG2; P.strideG2 = sG2;
     P.R1 = hrR1; P.flag = hrFlag; P.QT = QT; P.strideQT = sQT; P.nxp = 0; P.Xs = hrXs; P.strideXs = sXs;
+    P.Xch = reinterpret_cast<unsigned long long*>(hrG2); P.strideXch = sG2; P.na_shift = 0;
+    P.Xsx = reinterpret_cast<unsigned long long*>(hrXsx); P.strideXsx = sXsx; P.rcs_max = (int)hr_rcs;
+    ND4_HIP(hipMemsetAsync(hrXsx, 0, sizeof(double) * (size_t)batch * sXsx, h->stream));
+    ND4_HIP(hipMemsetAsync(hrG2, 0, sizeof(double) * (size_t)batch * sG2, h->stream));
+    ND4_HIP(hipMemsetAsync(hrFlag, 0, sizeof(int) * (size_t)batch, h->stream));
     P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 0; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
     static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
     P.stamps = nullptr; P.stamp_slot = 0;
@@ -2139,7 +2589,7 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
   Nd4WsScope scope(h);
   void* p = nullptr;
   const int parts = (M + NB + 511) / 512 + 1;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (NB + (2 * parts + 1) * 256 + 256 + 2) + 64, &p));
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (NB + (3 * parts + 1) * 256 + 256 + 2) + 64, &p));
   double* taus = static_cast<double*>(p);
   const long sW = (long)M * NB;
   const int nb = M < NB ? M : NB;
@@ -2153,7 +2603,10 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     P.Wm = A; P.M = M; P.N = NB; P.ld = NB; P.strideW = sW; P.Vall = V; P.ldv = NB; P.strideV = sW; P.Tall = T; P.strideT = NB * NB;
     P.taus = taus; P.strideTau = NB; P.Xp = nullptr; P.strideXp = 0;
     P.Gp = d; P.strideGp = (long)(parts + 1) * 256; d += (size_t)batch * P.strideGp;
-    P.G2p = d; P.strideG2 = (long)parts * 256; d += (size_t)batch * P.strideG2;
+    P.G2p = d; P.strideG2 = (long)parts * 512; d += (size_t)batch * P.strideG2;
+    P.Xch = reinterpret_cast<unsigned long long*>(P.G2p); P.strideXch = P.strideG2; P.na_shift = 0;
+    P.Xsx = nullptr; P.strideXsx = 0; P.rcs_max = 1;
+    ND4_HIP(hipMemsetAsync(P.G2p, 0, sizeof(double) * (size_t)batch * P.strideG2, h->stream));
     P.R1 = d; d += (size_t)batch * 256;
     P.flag = reinterpret_cast<int*>(d);
     P.QT = nullptr; P.strideQT = 0; P.nxp = 0; P.Xs = nullptr; P.strideXs = 0;
