@@ -861,14 +861,14 @@ __device__ __forceinline__ void qx_st(qx_u64* slot, int v, double x, unsigned ta
   __hip_atomic_store(slot + 2 * v, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(slot + 2 * v + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// fixed-order sum of entry v over the n slots (512 words apart); ok stays true only if every word carried the tag
-__device__ __forceinline__ double qx_sum(const qx_u64* __restrict__ slots, int v, int n, unsigned tag, bool& ok) {
+// fixed-order sum of entry v over the n slots (`stride` words apart); ok stays true only if every word carried the tag
+__device__ __forceinline__ double qx_sum(const qx_u64* __restrict__ slots, int v, int n, unsigned tag, bool& ok, long stride = 512) {
   double x = 0.0;
   for (int p0 = 0; p0 < n; p0 += 8) {
     qx_u64 w0[8], w1[8];
 #pragma unroll
     for (int p = 0; p < 8; p++) {
-      const qx_u64* sp = slots + (long)(p0 + p < n ? p0 + p : 0) * 512 + 2 * v;
+      const qx_u64* sp = slots + (long)(p0 + p < n ? p0 + p : 0) * stride + 2 * v;
       w0[p] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       w1[p] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1410,7 +1410,10 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
 // panel: the side work of this launch starts one block later (na_shift) and covers W and Q^T in one go.
 // A flagged panel: workgroup 0 runs qr_panel_row_body (R > 0; tall panels: qr_panel_flagged in a launch of its own, as before) and
 // nobody writes partials of X: the next launch A forms X itself (qrh_gram), the last panel's narrow update goes through qrh_x_flagged.
-template <int R>
+constexpr long QX_ROW_SLOT = 2560;   // words per row workgroup: values [0,256) G, [256,512) X of the next block, [512,768) top-tile Gram, 768 "stores are out", [1024,1280) Gram of Q1
+// MERGED: phase A in the same launch as well — the previous reflector on the panel's own columns, the partial Gram matrices and the
+// partial X of the NEXT panel's block cross in a first exchange, so a panel is ONE launch (all side work rides in it).
+template <int R, bool MERGED>
 __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   __shared__ double s_buf[QRH_SMEM];
   __shared__ double s_G[256], s_R[256], s_Ri[256], s_db[16];
@@ -1425,36 +1428,175 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   const int rb = ub + (g * 8 + wave) * 64;                                  // phase A's row partition
   const unsigned tag = (unsigned)(j0 / NB + 1);
   qx_u64* slots = P.Xch + mat * P.strideXch;
+  qx_u64* myslot = slots + (long)g * QX_ROW_SLOT;
   double* Xdst = P.Xp + mat * P.strideXp + (long)g * 256;
   qrh_stamp(P, 0);
-  // ---- the next panel's columns: the previous reflector for this workgroup's rows (kept in cs for the partial X below) ----
   d4 csb[1][4];
   d4 (&cs)[4] = csb[0];
-  if (nc > 0 && P.pj0 >= 0) {
-    qrh_apply_rows<1>(s_buf, P.Xs + mat * P.strideXs, 0, P.nrc, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
-                      P.Vall + mat * P.strideV + ub, P.ldv, A + c0, ld, nc, rb, M, csb);
-    __syncthreads();
-  } else {
+  double a[4][4];
+  if constexpr (MERGED) {
+    // ---- phase A: the previous reflector on the panel's own columns, partial Gram matrices, partial X of the next block ----
+    d4 cc[1][4];
+    d4 (&c)[4] = cc[0];
+    if (P.pj0 >= 0) {
+      const double* Xsrc = P.Xp + mat * P.strideXp;
+      int nx = P.nxp;
+      if (P.flag[mat]) {                                              // the previous panel was flagged: no partials of X (see qrh_gram)
+        double* mine = P.Xp + mat * P.strideXp + (long)g * 256;
+        qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)ub * P.ldv + ub, P.ldv, A + (long)ub * ld + j0, ld, M - ub, NB, mine);
+        __syncthreads();
+        Xsrc = mine; nx = 1;
+      }
+      qrh_apply_rows<1>(s_buf, Xsrc, 0, nx, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                        P.Vall + mat * P.strideV + ub, P.ldv, A + j0, ld, NB, rb, M, cc);
+      __syncthreads();
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < 4; q++) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int rc = rb + q * 16 + fk + 4 * r;
-        cs[q][r] = (rc >= j0 && rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
+        for (int r = 0; r < 4; r++) {
+          const int rc = rb + q * 16 + fk + 4 * r;
+          c[q][r] = (rc >= 0 && rc < M) ? A[(long)rc * ld + j0 + fx] : 0.0;
+        }
       }
     }
+    qrh_stamp(P, 1);
+    d4 g0 = d4{0.0, 0.0, 0.0, 0.0}, g1 = g0, gt = g0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ti = (g * 8 + wave) * 4 + q;                          // tile 0: the 16 rows above the panel, tile 1: its top block
+      if (ti == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) gt = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][r], c[q][r], gt, 0, 0, 0);
+      } else if (ti >= 2) {
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][0], c[q][0], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][1], c[q][1], g1, 0, 0, 0);
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][2], c[q][2], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[q][3], c[q][3], g1, 0, 0, 0);
+      }
+    }
+    // partial X = V^T C of the next panel's block over this workgroup's rows (the previous reflector; slab images)
+    d4 xn0 = d4{0.0, 0.0, 0.0, 0.0}, xn1 = xn0;
+    const bool nextupd = nc > 0 && P.pj0 >= 0;
+    if (nextupd) {
+      const double* Vp = P.Vall + mat * P.strideV + ub;
+      double vs[16], cn[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int r = rb + 4 * u + fk;
+        const bool rok = r >= 0 && r < M;
+        vs[u] = rok ? Vp[(long)r * P.ldv + fx] : 0.0;
+        cn[u] = (rok && fx < nc) ? A[(long)r * ld + c0 + fx] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        xn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[u], cn[u], xn0, 0, 0, 0);
+        xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[u + 1], cn[u + 1], xn1, 0, 0, 0);
+      }
+    }
+    // the panel tile from its accumulator image to the A-operand image (tile 0 lies above the panel: zero), through the wave's own LDS
+    {
+      double* sw = s_buf + 8 * 256 + wave * 272;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ti = (g * 8 + wave) * 4 + q;
+#pragma unroll
+        for (int r = 0; r < 4; r++) sw[(fk + 4 * r) * 17 + fx] = ti >= 1 ? c[q][r] : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) a[q][kk] = sw[fx * 17 + 4 * fk + kk];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    // first exchange: G partial, X partial, (workgroup 0, wave 0) the top tile's Gram matrix
+#pragma unroll
+    for (int r = 0; r < 4; r++) s_buf[wave * 256 + (fk + 4 * r) * 16 + fx] = g0[r] + g1[r];
+    if (g == 0 && wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) qx_st(myslot, 512 + (fk + 4 * r) * 16 + fx, gt[r], tag);
+    }
+    __syncthreads();
+    if (t < 256) {
+      double xs = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
+      qx_st(myslot, t, xs, tag);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) s_buf[wave * 256 + (fk + 4 * r) * 16 + fx] = xn0[r] + xn1[r];
+    __syncthreads();
+    if (t >= 256) {
+      double xs = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + (t - 256)];
+      qx_st(myslot, t, xs, tag);
+    }
+    qrh_stamp(P, 2);
+    double* xmine = P.Xs + mat * P.strideXs + (long)g * 256;           // (the side partials are not used in this mode)
+    if (t < 256) {
+      double x = 0.0, xn = 0.0, top = 0.0;
+      int spins = 0;
+      for (;;) {
+        bool ok = true;
+        x = qx_sum(slots, t, P.nrow, tag, ok, QX_ROW_SLOT);
+        if (nextupd) xn = qx_sum(slots, 256 + t, P.nrow, tag, ok, QX_ROW_SLOT);
+        const qx_u64 w0 = __hip_atomic_load(slots + 2 * (512 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const qx_u64 w1 = __hip_atomic_load(slots + 2 * (512 + t) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
+        top = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+        if (ok || ++spins > QX_SPIN_LIMIT) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_G[t] = x + top;
+      if (t % 17 == 0) s_db[t / 17] = x;                               // column sums of squares below the top block
+      if (nextupd) xmine[t] = xn;                                      // (read back by this same thread in qrh_apply_rows)
+    }
+    if (t == 0) s_emax = 0;
+    __syncthreads();
+    qrh_stamp(P, 3);
+    // the next panel's columns: the previous reflector for this workgroup's rows, X now complete (kept in cs for the partial X below)
+    if (nextupd) {
+      qrh_apply_rows<1>(s_buf, xmine, 0, 1, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                        P.Vall + mat * P.strideV + ub, P.ldv, A + c0, ld, nc, rb, M, csb);
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int rc = rb + q * 16 + fk + 4 * r;
+          cs[q][r] = (rc >= j0 && rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
+        }
+      }
+    }
+  } else {
+    // ---- the next panel's columns: the previous reflector for this workgroup's rows (kept in cs for the partial X below) ----
+    if (nc > 0 && P.pj0 >= 0) {
+      qrh_apply_rows<1>(s_buf, P.Xs + mat * P.strideXs, 0, P.nrc, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
+                        P.Vall + mat * P.strideV + ub, P.ldv, A + c0, ld, nc, rb, M, csb);
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int rc = rb + q * 16 + fk + 4 * r;
+          cs[q][r] = (rc >= j0 && rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
+        }
+      }
+    }
+    qrh_load_rows(A, ld, j0, rb, M, a, j0);
+    if (t < 256) {
+      const double gb = qrh_sum_parts(P.Gp + mat * P.strideGp + 256 + t, P.ngp);
+      s_G[t] = gb + P.Gp[mat * P.strideGp + t];
+      if (t % 17 == 0) s_db[t / 17] = gb;                             // column sums of squares below the top block
+    }
+    if (t == 0) s_emax = 0;
+    __syncthreads();
+    qrh_stamp(P, 1);
   }
   // ---- phase B: R1 = chol(G), the fall-back decision ----
-  double a[4][4];
-  qrh_load_rows(A, ld, j0, rb, M, a, j0);
-  if (t < 256) {
-    const double gb = qrh_sum_parts(P.Gp + mat * P.strideGp + 256 + t, P.ngp);
-    s_G[t] = gb + P.Gp[mat * P.strideGp + t];
-    if (t % 17 == 0) s_db[t / 17] = gb;                               // column sums of squares below the top block
-  }
-  if (t == 0) s_emax = 0;
-  __syncthreads();
-  qrh_stamp(P, 1);
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
     bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
@@ -1465,10 +1607,29 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   }
   __syncthreads();
   const int flag = s_flag;                                            // (the same in every row workgroup: same sums in the same order)
-  qrh_stamp(P, 2);
   if (g == 0 && t == 0) P.flag[mat] = flag;
   if (flag) {
     if constexpr (R > 0) {
+      if constexpr (MERGED) {
+        // the panel's columns were written by all row workgroups of THIS launch: every workgroup pushes its stores out (release:
+        // write back the L2) and says so; workgroup 0 waits for all, invalidates (acquire) and runs the classic panel. Rare path.
+        __threadfence();
+        __syncthreads();
+        if (t == 0) qx_st(myslot, 768, 1.0, tag);
+        if (g == 0) {
+          if (t < P.nrow) {
+            int spins = 0;
+            for (;;) {
+              bool ok = true;
+              (void)qx_sum(slots + (long)t * QX_ROW_SLOT, 768, 1, tag, ok, QX_ROW_SLOT);
+              if (ok || ++spins > QX_SPIN_LIMIT) break;
+              __builtin_amdgcn_s_sleep(4);
+            }
+          }
+          __syncthreads();
+          __threadfence();
+        }
+      }
       if (g == 0) qr_panel_row_body<(R > 0 ? R : 1)>(mat, P.Wm, M, ld, P.strideW, P.Vall, P.ldv, P.strideV, P.Tall, P.strideT, P.taus, P.strideTau, j0, NB);
     }
     return;
@@ -1506,7 +1667,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     double xs = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
-    qx_st(slots + (long)g * 512, t, xs, tag);
+    qx_st(myslot, 1024 + t, xs, tag);
   }
   qrh_stamp(P, 3);
   double x = 0.0;
@@ -1514,7 +1675,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     int spins = 0;
     for (;;) {
       bool ok = true;
-      x = qx_sum(slots, t, P.nrow, tag, ok);
+      x = qx_sum(slots, 1024 + t, P.nrow, tag, ok, QX_ROW_SLOT);
       if (ok || ++spins > QX_SPIN_LIMIT) break;
       __builtin_amdgcn_s_sleep(2);
     }
@@ -2117,6 +2278,25 @@ struct QrhHost {
       const int sh = (pj0 >= 0 && next_cols) ? 1 : 0;
       const int nwp = pj0 >= 0 ? (P.nnw - sh + 1) / 2 : 0, nqp = pj0 >= 0 ? (P.nqb + 1) / 2 : 0;
       const bool sf = !sf_off && P.Xsx != nullptr;
+      static const bool mg_off = [] { const char* e = getenv("ND4HIP_QR_NO_MERGED"); return e && *e && *e != '0'; }();
+      if ((sf || side_all == 0) && !mg_off) {
+        // ONE launch per panel: phase A rides in front of B and C (first exchange: Gram partials + partial X of the next block)
+        P.na_shift = sh;
+        P.nrow = nA; P.ngp = 0; P.nseg = 0; add_seg(SEG_F, 0, (nwp + nqp) * P.nrc);
+        const dim3 gm((unsigned)(nA + seg_total()), (unsigned)batch);
+        if (m <= 512)       hipLaunchKernelGGL((qrh_bc<1, true>), gm, dim3(512), 0, h->stream, P);
+        else if (m <= 1024) hipLaunchKernelGGL((qrh_bc<2, true>), gm, dim3(512), 0, h->stream, P);
+        else if (m <= 2048) hipLaunchKernelGGL((qrh_bc<4, true>), gm, dim3(512), 0, h->stream, P);
+        else {
+          hipLaunchKernelGGL((qrh_bc<0, true>), gm, dim3(512), 0, h->stream, P);
+          hipLaunchKernelGGL(qr_panel_flagged, dim3((unsigned)batch), dim3(1024), 0, h->stream, P.Wm, P.M, P.ld, P.strideW, P.Vall, P.ldv, P.strideV,
+                             P.Tall, P.strideT, P.taus, P.strideTau, j0, NB, P.flag);
+        }
+        P.na_shift = 0;
+        pj0 = j0; P.nxp = nA; P.nseg = 0; P.stamp_slot++; fused_last = true;
+        ND4_HIP(hipGetLastError());
+        return 0;
+      }
       P.nrow = nA; P.ngp = 0; P.nseg = 0;
       static const int sf_a = [] { const char* e = getenv("ND4HIP_QR_SIDE_IN_A"); return e ? atoi(e) : 0; }();   // percent of the W pairs that ride in launch A
       const int nwa = nwp * sf_a / 100;
@@ -2127,11 +2307,11 @@ struct QrhHost {
       P.nrow = nA; P.ngp = nA; P.nseg = 0;
       if (sf) add_seg(SEG_F, nwa * P.nrc, (nwp - nwa + nqp) * P.nrc); else add_seg(SEG_NA, 0, (nwp + nqp) * P.nrc);
       const dim3 gc((unsigned)(nA + seg_total()), (unsigned)batch);
-      if (m <= 512)       hipLaunchKernelGGL(qrh_bc<1>, gc, dim3(512), 0, h->stream, P);
-      else if (m <= 1024) hipLaunchKernelGGL(qrh_bc<2>, gc, dim3(512), 0, h->stream, P);
-      else if (m <= 2048) hipLaunchKernelGGL(qrh_bc<4>, gc, dim3(512), 0, h->stream, P);
+      if (m <= 512)       hipLaunchKernelGGL((qrh_bc<1, false>), gc, dim3(512), 0, h->stream, P);
+      else if (m <= 1024) hipLaunchKernelGGL((qrh_bc<2, false>), gc, dim3(512), 0, h->stream, P);
+      else if (m <= 2048) hipLaunchKernelGGL((qrh_bc<4, false>), gc, dim3(512), 0, h->stream, P);
       else {
-        hipLaunchKernelGGL(qrh_bc<0>, gc, dim3(512), 0, h->stream, P);
+        hipLaunchKernelGGL((qrh_bc<0, false>), gc, dim3(512), 0, h->stream, P);
         hipLaunchKernelGGL(qr_panel_flagged, dim3((unsigned)batch), dim3(1024), 0, h->stream, P.Wm, P.M, P.ld, P.strideW, P.Vall, P.ldv, P.strideV,
                            P.Tall, P.strideT, P.taus, P.strideTau, j0, NB, P.flag);
       }
@@ -2282,7 +2462,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   const bool hr_tall = !hr_off && !la_off && batch <= 8 && M > 2048 && M <= 16384 && L >= 256 && (L % NB == 0 || M - (L / NB) * NB <= 2048);
   const bool use_hr = (lookahead && !hr_off && batch <= 8) || hr_tall;    // multi-workgroup panels (CholeskyQR2 + compact orthogonal completion)
   const int hr_parts = (M + NB + 511) / 512 + 1;
-  const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * 512 : 0, sR1 = use_hr ? 256 : 0;   // G2: partials (3 launches) or 512 tagged words per row workgroup (qrh_bc)
+  const long sGp = use_hr ? (long)(hr_parts + 1) * 256 : 0, sG2 = use_hr ? (long)hr_parts * QX_ROW_SLOT : 0, sR1 = use_hr ? 256 : 0;   // G2: partials (3 launches) or 512 tagged words per row workgroup (qrh_bc)
   const long hr_rcs = (M + 511) / 512;
   const long sXs = use_hr ? ((N + NB - 1) / NB + (use_qt ? (M + NB - 1) / NB : 0)) * hr_rcs * 256 : 0;   // side work: [column block][row chunk][256]
   const long sXsx = 2 * sXs;                                 // fused side work: 512 tagged words per (column block, row chunk)
@@ -2589,7 +2769,7 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
   Nd4WsScope scope(h);
   void* p = nullptr;
   const int parts = (M + NB + 511) / 512 + 1;
-  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (NB + (3 * parts + 1) * 256 + 256 + 2) + 64, &p));
+  ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (NB + (parts + 1) * 256 + parts * QX_ROW_SLOT + 256 + 2) + 64, &p));
   double* taus = static_cast<double*>(p);
   const long sW = (long)M * NB;
   const int nb = M < NB ? M : NB;
@@ -2603,7 +2783,7 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     P.Wm = A; P.M = M; P.N = NB; P.ld = NB; P.strideW = sW; P.Vall = V; P.ldv = NB; P.strideV = sW; P.Tall = T; P.strideT = NB * NB;
     P.taus = taus; P.strideTau = NB; P.Xp = nullptr; P.strideXp = 0;
     P.Gp = d; P.strideGp = (long)(parts + 1) * 256; d += (size_t)batch * P.strideGp;
-    P.G2p = d; P.strideG2 = (long)parts * 512; d += (size_t)batch * P.strideG2;
+    P.G2p = d; P.strideG2 = (long)parts * QX_ROW_SLOT; d += (size_t)batch * P.strideG2;
     P.Xch = reinterpret_cast<unsigned long long*>(P.G2p); P.strideXch = P.strideG2; P.na_shift = 0;
     P.Xsx = nullptr; P.strideXsx = 0; P.rcs_max = 1;
     ND4_HIP(hipMemsetAsync(P.G2p, 0, sizeof(double) * (size_t)batch * P.strideG2, h->stream));
