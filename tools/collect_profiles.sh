@@ -18,6 +18,7 @@ ks bidiag2048 python3 $R/tools/prof_hess.py 2048 bidiag
 ks lu_solve2048 python3 $R/tools/prof_ops.py lusolve
 ks qr4096 python3 $R/tools/prof_ops.py qr --n 4096 --reps 2
 ks lu_qr_8192 python3 $R/tools/prof_ops.py lu qr --n 8192 --reps 1
+ks lu4096 python3 $R/tools/prof_ops.py lu --n 4096 --reps 2
 pmc gemm_fetch FETCH_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_write WRITE_SIZE python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
 pmc gemm_busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 $R/bench.py --steps 5 --warmup 1 --no-ops --no-cpu-baseline
@@ -25,4 +26,8 @@ pmc lu8192_fetch FETCH_SIZE python3 $R/tools/prof_ops.py lu --n 8192 --reps 1
 pmc lu8192_write WRITE_SIZE python3 $R/tools/prof_ops.py lu --n 8192 --reps 1
 pmc svd_fetch FETCH_SIZE python3 $R/tools/prof_ops.py svd --reps 1
 pmc svd_write WRITE_SIZE python3 $R/tools/prof_ops.py svd --reps 1
+# the in-kernel exchange (tools/xwg_lat.hip) and the phase stamps of the one-launch QR panels / the multi-workgroup LU panels
+hipcc --offload-arch=gfx950 -O3 $R/tools/xwg_lat.hip -o $out/xwg_lat && timeout -k 10 120 $out/xwg_lat > $out/xwg_lat.txt 2>&1; rm -f $out/xwg_lat
+ND4HIP_QR_STAMPS=1 python3 $R/tools/prof_ops.py qr --n 2048 --reps 1 2>&1 | grep 'qrh stamp' > $out/qr2048_panel_phase_stamps.txt
+ND4HIP_LU_MW_R=2 ND4HIP_LU_STAMPS=1 ND4HIP_LU_NO_LOOKAHEAD=1 python3 $R/tools/prof_ops.py lu --n 4096 --reps 1 2>&1 | grep 'mw stamps' > $out/lu4096_mw_panel_phase_stamps.txt
 ls $out
