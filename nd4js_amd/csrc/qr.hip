@@ -1434,11 +1434,53 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   d4 csb[1][4];
   d4 (&cs)[4] = csb[0];
   double a[4][4];
+  __shared__ double s_T2[256], s_Xs[256], s_Xn[256];
+  d4 cnx[4]; double avp[4][4]; bool nextupd = false;       // MERGED: the next block's tile, the previous reflector's rows
+  // the next block through the previous reflector for this workgroup's rows: C -= V (T^T X), -T^T X in s_Xn
+  auto apply_next = [&]() {
+    double bwn[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) bwn[kk] = s_Xn[(4 * fk + kk) * 16 + fx];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) cnx[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(avp[q][kk], bwn[kk], cnx[q], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        if (rc >= 0 && rc < M && fx < nc) A[(long)rc * ld + c0 + fx] = cnx[q][r];
+      }
+    }
+  };
   if constexpr (MERGED) {
     // ---- phase A: the previous reflector on the panel's own columns, partial Gram matrices, partial X of the next block ----
-    d4 cc[1][4];
-    d4 (&c)[4] = cc[0];
-    if (P.pj0 >= 0) {
+    // All loads first: the own tile and the next block's tile in the accumulator image (== slab image: slab u = 4 q + r), the
+    // previous reflector's rows as A operands (avp) and as slabs (vs). The next block's tile and avp stay in registers until the
+    // block is updated in the shadow of the second exchange.
+    d4 c[4];
+    const bool havep = P.pj0 >= 0;
+    nextupd = nc > 0 && havep;
+    const double* Vp = P.Vall + mat * P.strideV + ub;
+    double vs[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rc = rb + q * 16 + fk + 4 * r;
+        const bool rok = rc >= 0 && rc < M;
+        c[q][r] = rok ? A[(long)rc * ld + j0 + fx] : 0.0;
+        cnx[q][r] = (rok && fx < nc && (nextupd || rc >= j0)) ? A[(long)rc * ld + c0 + fx] : 0.0;
+        vs[4 * q + r] = (rok && nextupd) ? Vp[(long)rc * P.ldv + fx] : 0.0;
+      }
+      const int ra = rb + q * 16 + fx;
+      if (havep && ra >= 0 && ra < M) {
+        const double2 v0 = *reinterpret_cast<const double2*>(Vp + (long)ra * P.ldv + 4 * fk);
+        const double2 v1 = *reinterpret_cast<const double2*>(Vp + (long)ra * P.ldv + 4 * fk + 2);
+        avp[q][0] = v0.x; avp[q][1] = v0.y; avp[q][2] = v1.x; avp[q][3] = v1.y;
+      } else { avp[q][0] = avp[q][1] = avp[q][2] = avp[q][3] = 0.0; }
+    }
+    const int i = (t & 255) / 16, j = t % 16;
+    if (havep) {
       const double* Xsrc = P.Xp + mat * P.strideXp;
       int nx = P.nxp;
       if (P.flag[mat]) {                                              // the previous panel was flagged: no partials of X (see qrh_gram)
@@ -1447,18 +1489,33 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
         __syncthreads();
         Xsrc = mine; nx = 1;
       }
-      qrh_apply_rows<1>(s_buf, Xsrc, 0, nx, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
-                        P.Vall + mat * P.strideV + ub, P.ldv, A + j0, ld, NB, rb, M, cc);
+      if (t < 256) {
+        s_buf[t] = qrh_sum_parts(Xsrc + t, nx);
+        s_T2[t] = P.Tall[mat * P.strideT + (long)(ub / NB) * NB * NB + t];
+      }
       __syncthreads();
-    } else {
+      double wv = 0.0;
+      if (t < 256) {
+#pragma unroll
+        for (int l = 0; l < NB; l++) wv += s_T2[l * 16 + i] * s_buf[l * 16 + j];               // T^T X
+      }
+      __syncthreads();
+      if (t < 256) s_buf[t] = -wv;
+      __syncthreads();
+      double bwp[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) bwp[kk] = s_buf[(4 * fk + kk) * 16 + fx];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
 #pragma unroll
+        for (int kk = 0; kk < 4; kk++) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(avp[q][kk], bwp[kk], c[q], 0, 0, 0);
+#pragma unroll
         for (int r = 0; r < 4; r++) {
           const int rc = rb + q * 16 + fk + 4 * r;
-          c[q][r] = (rc >= 0 && rc < M) ? A[(long)rc * ld + j0 + fx] : 0.0;
+          if (rc >= 0 && rc < M) A[(long)rc * ld + j0 + fx] = c[q][r];
         }
       }
+      __syncthreads();                                                  // s_buf is reused below
     }
     qrh_stamp(P, 1);
     d4 g0 = d4{0.0, 0.0, 0.0, 0.0}, g1 = g0, gt = g0;
@@ -1477,21 +1534,13 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     }
     // partial X = V^T C of the next panel's block over this workgroup's rows (the previous reflector; slab images)
     d4 xn0 = d4{0.0, 0.0, 0.0, 0.0}, xn1 = xn0;
-    const bool nextupd = nc > 0 && P.pj0 >= 0;
     if (nextupd) {
-      const double* Vp = P.Vall + mat * P.strideV + ub;
-      double vs[16], cn[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int r = rb + 4 * u + fk;
-        const bool rok = r >= 0 && r < M;
-        vs[u] = rok ? Vp[(long)r * P.ldv + fx] : 0.0;
-        cn[u] = (rok && fx < nc) ? A[(long)r * ld + c0 + fx] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u += 2) {
-        xn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[u], cn[u], xn0, 0, 0, 0);
-        xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[u + 1], cn[u + 1], xn1, 0, 0, 0);
+      for (int q = 0; q < 4; q++) {
+        xn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[4 * q + 0], cnx[q][0], xn0, 0, 0, 0);
+        xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[4 * q + 1], cnx[q][1], xn1, 0, 0, 0);
+        xn0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[4 * q + 2], cnx[q][2], xn0, 0, 0, 0);
+        xn1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[4 * q + 3], cnx[q][3], xn1, 0, 0, 0);
       }
     }
     // the panel tile from its accumulator image to the A-operand image (tile 0 lies above the panel: zero), through the wave's own LDS
@@ -1533,7 +1582,6 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
       qx_st(myslot, t, xs, tag);
     }
     qrh_stamp(P, 2);
-    double* xmine = P.Xs + mat * P.strideXs + (long)g * 256;           // (the side partials are not used in this mode)
     if (t < 256) {
       double x = 0.0, xn = 0.0, top = 0.0;
       int spins = 0;
@@ -1550,25 +1598,17 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
       }
       s_G[t] = x + top;
       if (t % 17 == 0) s_db[t / 17] = x;                               // column sums of squares below the top block
-      if (nextupd) xmine[t] = xn;                                      // (read back by this same thread in qrh_apply_rows)
+      s_Xs[t] = xn;
     }
     if (t == 0) s_emax = 0;
     __syncthreads();
     qrh_stamp(P, 3);
-    // the next panel's columns: the previous reflector for this workgroup's rows, X now complete (kept in cs for the partial X below)
-    if (nextupd) {
-      qrh_apply_rows<1>(s_buf, xmine, 0, 1, P.Tall + mat * P.strideT + (long)(ub / NB) * NB * NB,
-                        P.Vall + mat * P.strideV + ub, P.ldv, A + c0, ld, nc, rb, M, csb);
-      __syncthreads();
-    } else {
+    // while wave 0 walks the elimination chain below, waves 4..7 form -T^T X for the next block
+    if (nextupd && t >= 256) {
+      double wv = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int rc = rb + q * 16 + fk + 4 * r;
-          cs[q][r] = (rc >= j0 && rc < M && fx < nc) ? A[(long)rc * ld + c0 + fx] : 0.0;
-        }
-      }
+      for (int l = 0; l < NB; l++) wv += s_T2[l * 16 + i] * s_Xs[l * 16 + j];
+      s_Xn[t - 256] = -wv;
     }
   } else {
     // ---- the next panel's columns: the previous reflector for this workgroup's rows (kept in cs for the partial X below) ----
@@ -1609,6 +1649,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   const int flag = s_flag;                                            // (the same in every row workgroup: same sums in the same order)
   if (g == 0 && t == 0) P.flag[mat] = flag;
   if (flag) {
+    if constexpr (MERGED) { if (nextupd) apply_next(); }          // (the next launch needs the block whatever happens to this panel)
     if constexpr (R > 0) {
       if constexpr (MERGED) {
         // the panel's columns were written by all row workgroups of THIS launch: every workgroup pushes its stores out (release:
@@ -1668,6 +1709,11 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
 #pragma unroll
     for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
     qx_st(myslot, 1024 + t, xs, tag);
+  }
+  if constexpr (MERGED) {                                              // in the shadow of the exchange: the next block
+    if (nextupd) apply_next();
+#pragma unroll
+    for (int q = 0; q < 4; q++) cs[q] = cnx[q];
   }
   qrh_stamp(P, 3);
   double x = 0.0;
