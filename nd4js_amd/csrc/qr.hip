@@ -1461,6 +1461,18 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     const bool havep = P.pj0 >= 0;
     nextupd = nc > 0 && havep;
     const double* Vp = P.Vall + mat * P.strideV + ub;
+    const bool prevflag = havep && P.flag[mat] != 0;                  // the previous panel was flagged: no partials of X (see qrh_gram)
+    // first the loads that head the dependent chain of the own-column update (loads return in order): X partials and T
+    double xsum0 = 0.0, tprev = 0.0, xp8[8];
+#pragma unroll
+    for (int p8 = 0; p8 < 8; p8++) xp8[p8] = 0.0;
+    if (havep && t < 256) {
+      if (!prevflag) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; p8++) if (p8 < P.nxp) xp8[p8] = P.Xp[mat * P.strideXp + (long)p8 * 256 + t];   // (summed below, after the tile loads are under way)
+      }
+      tprev = P.Tall[mat * P.strideT + (long)(ub / NB) * NB * NB + t];
+    }
     double vs[16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -1481,17 +1493,20 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     }
     const int i = (t & 255) / 16, j = t % 16;
     if (havep) {
-      const double* Xsrc = P.Xp + mat * P.strideXp;
-      int nx = P.nxp;
-      if (P.flag[mat]) {                                              // the previous panel was flagged: no partials of X (see qrh_gram)
+      if (prevflag) {
         double* mine = P.Xp + mat * P.strideXp + (long)g * 256;
         qrh_x_full(s_buf, P.Vall + mat * P.strideV + (long)ub * P.ldv + ub, P.ldv, A + (long)ub * ld + j0, ld, M - ub, NB, mine);
         __syncthreads();
-        Xsrc = mine; nx = 1;
+        if (t < 256) xsum0 = mine[t];
+        __syncthreads();
       }
       if (t < 256) {
-        s_buf[t] = qrh_sum_parts(Xsrc + t, nx);
-        s_T2[t] = P.Tall[mat * P.strideT + (long)(ub / NB) * NB * NB + t];
+        if (!prevflag) {
+#pragma unroll
+          for (int p8 = 0; p8 < 8; p8++) xsum0 += xp8[p8];
+          if (P.nxp > 8) xsum0 += qrh_sum_parts(P.Xp + mat * P.strideXp + 8 * 256 + t, P.nxp - 8);
+        }
+        s_buf[t] = xsum0; s_T2[t] = tprev;
       }
       __syncthreads();
       double wv = 0.0;
