@@ -24,6 +24,7 @@
 #include "nd4hip_internal.h"
 #include <cstdlib>
 #include "dpp.h"
+#include "xchg.h"
 #include <type_traits>
 #include <cfloat>
 
@@ -854,34 +855,7 @@ __device__ __forceinline__ void qrh_apply_rows(double* __restrict__ s_w, const d
 }
 
 // ---- tagged words: the in-kernel exchange between co-resident workgroups (see qrh_bc) ----
-typedef unsigned long long qx_u64;
-constexpr int QX_SPIN_LIMIT = 1 << 20;
-__device__ __forceinline__ void qx_st(qx_u64* slot, int v, double x, unsigned tag) {
-  const qx_u64 bits = (qx_u64)__double_as_longlong(x), tg = (qx_u64)tag << 32;
-  __hip_atomic_store(slot + 2 * v, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(slot + 2 * v + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// fixed-order sum of entry v over the n slots (`stride` words apart); ok stays true only if every word carried the tag
-__device__ __forceinline__ double qx_sum(const qx_u64* __restrict__ slots, int v, int n, unsigned tag, bool& ok, long stride = 512) {
-  double x = 0.0;
-  for (int p0 = 0; p0 < n; p0 += 8) {
-    qx_u64 w0[8], w1[8];
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      const qx_u64* sp = slots + (long)(p0 + p < n ? p0 + p : 0) * stride + 2 * v;
-      w0[p] = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      w1[p] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int p = 0; p < 8; p++)
-      if (p0 + p < n) {
-        ok = ok && (unsigned)(w0[p] >> 32) == tag && (unsigned)(w1[p] >> 32) == tag;
-        x += __longlong_as_double((long long)((w1[p] << 32) | (w0[p] & 0xffffffffull)));
-      }
-  }
-  return x;
-}
-
+// (qx_st / qx_sum: xchg.h)
 // ---- side work of the panel launches: the previous reflector (panel pj0) on the other column blocks (trailing columns of W, then
 // Q^T), in two phases split over 512-row chunks like the panel itself: partial X = V^T C (SEG_NX, launch A), C -= V (T^T X)
 // (SEG_NA: the blocks of W in launch B, whose first one phase C reads; those of Q^T in launch C) ----
