@@ -993,7 +993,8 @@ __device__ __forceinline__ void qrh_side_fused(const QrhP& P, int mat, int e, do
       for (;;) {
         bool ok = true;
         x = qx_sum(base, en, P.nrc, tag, ok);
-        if (ok || ++spins > QX_SPIN_LIMIT) break;
+        if (ok) break;
+        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }    // a stuck exchange must not pass silently
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -1582,7 +1583,8 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
         const qx_u64 w1 = __hip_atomic_load(slots + 2 * (512 + t) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
         top = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
-        if (ok || ++spins > QX_SPIN_LIMIT) break;
+        if (ok) break;
+        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }    // a stuck exchange must not pass silently
         __builtin_amdgcn_s_sleep(2);
       }
       s_G[t] = x + top;
@@ -1711,7 +1713,8 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     for (;;) {
       bool ok = true;
       x = qx_sum(slots, 1024 + t, P.nrow, tag, ok, QX_ROW_SLOT);
-      if (ok || ++spins > QX_SPIN_LIMIT) break;
+      if (ok) break;
+      if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }      // a stuck exchange must not pass silently
       __builtin_amdgcn_s_sleep(2);
     }
     x -= (i == j) ? 1.0 : 0.0;                                         // E = Q1^T Q1 - I
