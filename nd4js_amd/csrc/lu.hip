@@ -446,9 +446,16 @@ template <int R, int PQ, bool STAMPS = false>
 __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, double* __restrict__ LU, int N, long strideM, int j0,
                                                  int32_t* __restrict__ ipiv, int nopivot, double* __restrict__ xbuf, int* __restrict__ stuck,
                                                  int P, unsigned long long* __restrict__ stamps, const double* __restrict__ stage,
-                                                 const double* __restrict__ stage_top) {
+                                                 const double* __restrict__ stage_top, const int fold_pj0 = -1) {
+  // fold_pj0 >= 0 (one row per thread only): the previous panel's work on THESE 16 columns happens here instead of in a launch of
+  // its own (lu_narrow_fused): every workgroup works out the interchanges, gathers the 16 x 16 block above the panel, solves
+  // U12 = L11^-1 A12 (redundantly) and updates its own rows, read from where the interchanges take them from, with 256 FMAs per row
+  // in the order of lu.js:71-72. Nothing is written before the first exchange: a row is only ever read from itself or from one of
+  // the 16 top rows, the top rows' sources are rows of some workgroup's tile, and no workgroup stores its tile (or U12: workgroup 0,
+  // at the end) before every workgroup has published its first column, i.e. has left this prologue.
   constexpr int T = 512, W = NB, RT = R * T, NWV = 8;
-  const bool prio = stage_top != nullptr || stage != nullptr;
+  const bool fold = R == 1 && fold_pj0 >= 0;
+  const bool prio = stage_top != nullptr || stage != nullptr || fold;
   __shared__ PivCand s_red[NWV];
   __shared__ double s_rows[NWV][W], s_j[W], s_u[W], s_dj[W];
   __shared__ int s_piv;
@@ -459,12 +466,72 @@ __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, dou
   const int rbase = j0 + w * RT;                  // first row of this workgroup; row of (thread t, slot i) = rbase + t + T * i
   const bool vec = (N & 1) == 0;
   double a[R][W];
+  __shared__ int s_piv2[NB], s_src2[2 * NB], s_dst2[2 * NB];
+  __shared__ double s_top2[NB][NB + 1], s_l2[NB][NB + 1];
+  if (fold) {
+    const int pj = fold_pj0;
+    if (t < NB) s_piv2[t] = nopivot ? pj + t : ip[pj + t];
+    if (t < NB * NB) { const int i = t / NB, j = t % NB; s_l2[i][j] = (j < i) ? A[(long)(pj + i) * N + pj + j] : 0.0; }
+    __syncthreads();
+    if (t < 2 * NB) {                                             // where the content of the 16 top rows / the 16 pivot rows comes from
+      const int k = t & (NB - 1);
+      const int dst = t < NB ? pj + k : s_piv2[k];
+      int pos = dst;
+#pragma unroll
+      for (int q = NB - 1; q >= 0; q--) {
+        const int ps = s_piv2[q];
+        pos = (pos == pj + q) ? ps : ((pos == ps) ? pj + q : pos);
+      }
+      s_src2[t] = pos;
+      s_dst2[t] = (t < NB || dst >= pj + NB) ? dst : -1;
+    }
+    __syncthreads();
+    if (t < NB * NB) { const int k = t / NB, c = t % NB; s_top2[k][c] = A[(long)s_src2[k] * N + j0 + c]; }
+    __syncthreads();
+    if (t < NB) {                                                 // U12 = L11^-1 A12, one thread per column
+      double x[NB];
+#pragma unroll
+      for (int i = 0; i < NB; i++) x[i] = s_top2[i][t];
+#pragma unroll
+      for (int i = 1; i < NB; i++) {
+        double acc = x[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) acc -= s_l2[i][j] * x[j];
+        x[i] = acc;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) s_top2[i][t] = x[i];
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < R; i++) {
     const int r = rbase + t + T * i;
 #pragma unroll
     for (int c = 0; c < W; c++) a[i][c] = 0.0;
-    if (r < N) {
+    if (r < N && fold) {
+      int srow = r;
+#pragma unroll
+      for (int k = 0; k < NB; k++) if (s_dst2[NB + k] == r) srow = s_src2[NB + k];
+      const double* lrow = A + (long)r * N + fold_pj0;
+      const double* vrow = A + (long)srow * N + j0;
+      double l[NB];
+      if (vec) {
+#pragma unroll
+        for (int c = 0; c < W; c += 2) {
+          const double2 lv = *reinterpret_cast<const double2*>(lrow + c), vv = *reinterpret_cast<const double2*>(vrow + c);
+          l[c] = lv.x; l[c + 1] = lv.y; a[i][c] = vv.x; a[i][c + 1] = vv.y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; c++) { l[c] = lrow[c]; a[i][c] = vrow[c]; }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+#pragma unroll
+        for (int c = 0; c < W; c++) a[i][c] -= l[j] * s_top2[j][c];       // lu.js:71-72, column j of L after column j - 1
+      }
+    } else if (r < N) {
       const double* src = stage != nullptr ? stage + (long)(r - j0) * W : A + (long)r * N + j0;
       if (vec || stage != nullptr) {
 #pragma unroll
@@ -496,7 +563,11 @@ __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, dou
       cand = better(cand, o);
     }
     const double wm = nd4dpp::wave_max(cand.mag);
-    const int wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
+    // the lowest row among the lanes that hold the maximum: with one row per thread (or a single such lane) that is the lowest such lane
+    const unsigned long long eqm = __builtin_amdgcn_ballot_w64(cand.mag == wm);
+    int wi;
+    if (R == 1 || __builtin_popcountll(eqm) == 1) wi = __builtin_amdgcn_readlane(cand.idx, (int)__builtin_ctzll(eqm));
+    else wi = nd4dpp::wave_min(cand.mag == wm ? cand.idx : 0x7fffffff);
     if (lane == 0) { s_red[wave].mag = wm; s_red[wave].idx = wi; }
 #pragma unroll
     for (int i = 0; i < R; i++)
@@ -636,6 +707,7 @@ __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, dou
   ND4_COL(0) ND4_COL(1) ND4_COL(2) ND4_COL(3) ND4_COL(4) ND4_COL(5) ND4_COL(6) ND4_COL(7)
   ND4_COL(8) ND4_COL(9) ND4_COL(10) ND4_COL(11) ND4_COL(12) ND4_COL(13) ND4_COL(14) ND4_COL(15)
 #undef ND4_COL
+  if (fold && w == 0 && t < NB * NB) A[(long)(fold_pj0 + t / NB) * N + j0 + t % NB] = s_top2[t / NB][t % NB];   // U12 (see the note at the top)
 #pragma unroll
   for (int i = 0; i < R; i++) {
     const int r = rbase + t + T * i;
@@ -662,11 +734,11 @@ template <int R, int PQ>
 __global__ __launch_bounds__(512) void lu_panel_mw_la(double* __restrict__ LU, int N, long strideM, int j0, int32_t* __restrict__ Pm,
                                                       int32_t* __restrict__ ipiv, int nopivot, double* __restrict__ xbuf,
                                                       int* __restrict__ stuck, int P, int pj0, int wide0,
-                                                      const double* __restrict__ stage, long strideStage, int full_end) {
+                                                      const double* __restrict__ stage, long strideStage, int full_end, int fold) {
   if ((int)blockIdx.x < P) {
     const double* sg = stage != nullptr ? stage + blockIdx.y * strideStage : nullptr;
     lu_panel_mw_body<R, PQ, false>(blockIdx.x, blockIdx.y, LU, N, strideM, j0, ipiv, nopivot, xbuf, stuck, P, nullptr,
-                                   sg != nullptr ? sg + NB * NB : nullptr, sg);
+                                   sg != nullptr ? sg + NB * NB : nullptr, sg, fold ? pj0 : -1);
     return;
   }
   lu_update_block<512, true>((int)blockIdx.x - P, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, Pm, full_end);
@@ -1048,21 +1120,24 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sStage, &stg));
     stage = static_cast<double*>(stg);
   }
+  // (ND4HIP_LU_NO_FOLD=1: the narrow update of a multi-workgroup panel's columns as a launch of its own, as for the short panels)
+  static const bool fold_off = [] { const char* e = getenv("ND4HIP_LU_NO_FOLD"); return e && *e && *e != '0'; }();
   auto la_range = [&](const int j_from, const int j_to, const int full_end, int* j_next) -> int {
     int pj0 = -1, j0 = j_from;
-    bool narrow_done = true;
+    bool narrow_done = true, folded = false;                  // folded: this panel's kernel does the previous panel's narrow update itself
     for (; j0 < j_to && N - j0 >= 64; j0 += NB) {
       const int m = N - j0;
       // the panel at pj0 has reached its own columns and the 16 behind them (the narrow launch: [pj0 + NB, pj0 + 2 NB) = this panel,
       // staged out of place by lu_narrow_fused); it still owes the columns from pj0 + 2 NB on, the columns left of it, and P
       const int wide0 = pj0 + 2 * NB;
       const int nupd = pj0 < 0 ? 0 : 1 + pj0 / NB + (wide0 < N ? (N - wide0 + NB - 1) / NB : 0);
-      const double* sg = (fused && pj0 >= 0) ? stage : nullptr;
+      const double* sg = (fused && pj0 >= 0 && !folded) ? stage : nullptr;
       const int pp = pj0 < 0 ? 0 : pj0;
+      const int fold_arg = folded ? 1 : 0;
       if (m > 2048) {
         const int Pw = (m + mw_rt - 1) / mw_rt;
         const dim3 grid((unsigned)(Pw + nupd), (unsigned)batch);
-#define ND4_MWLA(RR, PQ) hipLaunchKernelGGL((lu_panel_mw_la<RR, PQ>), grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, xbuf, stuck, Pw, pp, wide0, sg, sStage, full_end)
+#define ND4_MWLA(RR, PQ) hipLaunchKernelGGL((lu_panel_mw_la<RR, PQ>), grid, dim3(512), 0, h->stream, LU, N, strideM, j0, P, ipiv, nopivot, xbuf, stuck, Pw, pp, wide0, sg, sStage, full_end, fold_arg)
         if (mw_rt == 2048)      { if (Pw <= 4) ND4_MWLA(4, 1); else if (Pw <= 8) ND4_MWLA(4, 2); else ND4_MWLA(4, 4); }
         else if (mw_rt == 1024) { if (Pw <= 4) ND4_MWLA(2, 1); else if (Pw <= 8) ND4_MWLA(2, 2); else ND4_MWLA(2, 4); }
         else                    { if (Pw <= 4) ND4_MWLA(1, 1); else if (Pw <= 8) ND4_MWLA(1, 2); else ND4_MWLA(1, 4); }
@@ -1076,7 +1151,10 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
       const int c0 = j0 + NB;                                // the next panel's columns
       const bool more = c0 < j_to && N - c0 >= 64;           // another look-ahead panel follows: stage its columns out of place
       narrow_done = true;
-      if (fused && more) {
+      folded = false;
+      if (more && !fold_off && mw_rt == 512 && m - NB > 2048) {
+        folded = true;                                       // the next panel is a multi-workgroup one with one row per thread: it folds this in
+      } else if (fused && more) {
         hipLaunchKernelGGL(lu_narrow_fused, dim3((unsigned)((m - NB + 255) / 256), (unsigned)batch), dim3(256), 0, h->stream,
                            LU, N, strideM, ipiv, nopivot, j0, stage, sStage);
       } else if (c0 < full_end && c0 < N) {
