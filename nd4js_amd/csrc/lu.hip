@@ -6,8 +6,13 @@
 //              wave-shuffle + LDS arg-max (ties -> lowest row, exactly the reference's strict '>' scan,
 //              lu.js:48-52), in-panel row swap, multipliers and rank-1 update. lu_panel_row<R>: one thread per
 //              row, the R x 16 tile of each lane in registers (m <= 2048); lu_panel_row<R,W,1024>: the same on
-//              1024 threads with 8- / 4-column panels (m <= 4096 / 8192); lu_panel_global: 16 lanes
-//              per row / panel in global memory (anything taller).
+//              1024 threads with 8- / 4-column panels (m <= 4096 / 8192: batches too large for the next form);
+//              lu_panel_mw<R,PQ>: m > 2048, the rows over P <= 16 co-resident workgroups with ONE in-kernel exchange per column
+//              (tagged words, see the comment at lu_panel_mw_body) — 16 columns wide at any height up to 32768 rows;
+//              lu_panel_global: 16 lanes per row / panel in global memory (short tails).
+//   look-ahead lu_panel_row_la / lu_panel_mw_la: the panel shares its launch with everything the previous panel still owes the other
+//              columns (lu_colblock_update); between two panels only the next panel's 16 columns are updated (lu_narrow_fused, or
+//              folded into the multi-workgroup panel's prologue). N > 2048: outer blocks of 512 columns, TRSM + one MFMA product each.
 //   lu_laswp   applies the panel's nb row swaps to the columns left and right of it (lu.js:59-61 swaps full
 //              rows) and, in the same pass, U12 = L11^-1 * A12 for the columns to the right (unit lower
 //              16x16 in LDS), one thread per column -> coalesced.
