@@ -226,10 +226,15 @@ __device__ __forceinline__ bool hessb_reflector(double* __restrict__ s_v, double
   const int t = threadIdx.x, ii = i - 1;
   const double* x = (k == 0) ? H + (long)i * N : bk.nextrow;
   double m1 = 0.0;                                     // max |row[j]|, j < i-1
-  for (int c = t; c < i; c += T) {
-    const double xc = x[c];
-    s_v[c] = xc;
-    if (c < ii) m1 = fmax(m1, fabs(xc));
+  for (int c0 = t; c0 < i; c0 += 8 * T) {              // eight loads in flight at a time
+    double xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) xv[q] = (c0 + q * T < i) ? x[c0 + q * T] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int c = c0 + q * T;
+      if (c < i) { s_v[c] = xv[q]; if (c < ii) m1 = fmax(m1, fabs(xv[q])); }
+    }
   }
   m1 = block_max(m1, s_red);                           // (its barriers publish s_v)
   double* vrow = bk.vrows + (long)(N - 1 - i) * N;    // reflector number N-1-i (processing order)
@@ -282,7 +287,13 @@ __global__ __launch_bounds__(256) void hessb_pass(const double* __restrict__ H, 
     const int which = d / k, j = d % k;
     const double* M = (which == 0 ? bk.Wt : (which == 1 ? bk.Vt : bk.Yt)) + (long)j * N;
     double s = 0.0;
-    for (int r = lane; r < i; r += 64) s += M[r] * v[r];
+    for (int r0 = lane; r0 < i; r0 += 8 * 64) {                     // eight loads in flight at a time (see hessb_reduce)
+      double mv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) mv[q] = (r0 + 64 * q < i) ? M[r0 + 64 * q] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (r0 + 64 * q < i) s += mv[q] * v[r0 + 64 * q];
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) bk.dots[which * NBH + j] = s;
     return;
@@ -347,7 +358,14 @@ __global__ __launch_bounds__(256) void hessb_reduce(const double* __restrict__ H
     const int P = (i + BR - 1) / BR;
     double x = 0.0, y = 0.0;
     if (e < N) {
-      for (int p = grp; p < P; p += RG) x += ws.xpart[(long)p * N + e];
+      // (eight loads in flight at a time: a rolled loop of dependent load-add pairs costs a memory round trip per partial)
+      for (int p0 = grp; p0 < P; p0 += 8 * RG) {
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) xv[q] = (p0 + q * RG < P) ? ws.xpart[(long)(p0 + q * RG) * N + e] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) x += xv[q];
+      }
       // corrections: thread group grp takes the steps j = grp, grp + RG, ...
       for (int j = grp; j < k; j += RG) {
         const double wj = bk.Wt[(long)j * N + e], vj = bk.Vt[(long)j * N + e], yj = bk.Yt[(long)j * N + e];
