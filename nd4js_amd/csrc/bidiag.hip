@@ -354,13 +354,24 @@ __global__ __launch_bounds__(256) void bd2_rowpass(double* __restrict__ W, int M
   const double* rowi = W + (long)i * N;                 // read by every workgroup: its final form goes to rowfin, bd2_update stores it
   const int r = first + blockIdx.x * 4 + wave;           // this wave's row
   double m1 = 0.0;
-  for (int j = t; j < n; j += 256) {
-    double zj = 0.0;
-    for (int q = 0; q < P; q++) zj += zp[(long)q * N + first + j];             // the row parts of bd2_colpass, fixed order
-    s_z[j] = zj;
-    const double x = rowi[first + j] - zj;               // u_i = 1
-    s_v[j] = x;
-    if (j > 0) m1 = fmax(m1, fabs(x));
+  for (int j0 = t; j0 < n; j0 += 8 * 256) {             // eight entries per thread with all their loads in flight (a rolled loop of
+    double zj[8], xr[8];                                 // dependent global loads costs a memory round trip per entry)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { zj[e] = 0.0; xr[e] = (j0 + 256 * e < n) ? rowi[first + j0 + 256 * e] : 0.0; }
+    for (int q = 0; q < P; q++) {                        // the row parts of bd2_colpass, fixed order
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (j0 + 256 * e < n) zj[e] += zp[(long)q * N + first + j0 + 256 * e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int j = j0 + 256 * e;
+      if (j < n) {
+        s_z[j] = zj[e];
+        const double x = xr[e] - zj[e];                  // u_i = 1
+        s_v[j] = x;
+        if (j > 0) m1 = fmax(m1, fabs(x));
+      }
+    }
   }
   m1 = blk_max(m1, s_red);                               // (its barriers publish s_v)
   if (!has_right || m1 == 0.0) {                         // NORM.max === 0 -> continue (bidiag.js:67): no right reflector
