@@ -19,13 +19,18 @@ PEAK_HBM_GBS = 8000.0
 EPS = 2.220446049250313e-16
 
 
-def _median_ms(fn, h, reps=10, warm=2):
+def _median_ms(fn, h, reps=10, warm=2, prep=None):
+    """prep (optional) runs before every call, outside the timed region (e.g. restoring an operand that fn overwrites)."""
     for _ in range(warm):                  # workspace allocation, code load, clocks back up after an idle phase
+        if prep is not None:
+            prep()
         fn()
     torch.cuda.synchronize()
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     ms = []
     for _ in range(reps):
+        if prep is not None:
+            prep()
         h.timer_start()
         fn()
         ms.append(h.timer_stop())
@@ -247,33 +252,35 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
     return out
 
 
-def qr_panel(h, dev, M=2048, b=16, batch=256):
-    """One panel factorisation kernel (Householder geqr2 + larft of b = 16 columns) on its own: a single 2048-row panel (one
-    workgroup: a latency chain), 256 of them in one launch (one workgroup per matrix and per CU: the register tile of 4 rows x 16
-    columns per thread admits one workgroup per CU, so larger batches run at the same rate), and the throughput regime of shorter
-    panels, where the same kernel body runs on few waves with four rows per thread so that several workgroups share a CU: 2048
-    panels of 512 rows (128 threads each), 1024 of 1024 rows (256 threads), 4096 of 256 rows (one wave each)."""
+def qr_panel(h, dev, M=2048, b=16, batch=256, nbuf=8):
+    """One panel factorisation (16 columns: R, the reflector block V and its factor T) on its own, through its entry point
+    nd4hip_dgeqr2_panel_batched_dev: a single 2048-row panel (a latency chain), 256 of them in one launch (one workgroup of 8 waves
+    per panel and per CU), and shorter panels, where several workgroups share a CU: 2048 panels of 512 rows (2 waves each), 1024 of
+    1024 rows, 4096 of 256 rows. Algorithmic bytes 16 m b per panel (read once, V written once). Timing: `nbuf` calls back to back
+    on `nbuf` different inputs between two HIP events (so that neither the launch latency of a 50 us kernel nor a cache-resident
+    input counts), median of 10 such groups; the inputs are restored outside the timed region."""
     import ctypes
     from nd4js_amd import _lib
-    res = {"cols": b, "algorithmic_bytes_per_panel_row": 16 * b}
+    res = {"cols": b, "algorithmic_bytes_per_panel_row": 16 * b, "timing": "median of 10 groups of %d back-to-back calls on distinct inputs (HIP events)" % nbuf}
     for name, rows, nb in (("single", M, 1), ("batched", M, batch), ("batched_512rows", 512, 2048), ("batched_1024rows", 1024, 1024),
-                           ("batched_256rows", 256, 4096)):
+                           ("batched_256rows", 256, 4096), ("batched_1024x2048rows", M, 1024)):
+        nbf = nbuf if nb * rows <= 2048 * 512 else 4
         A = dev.fill_uniform(21, (nb, rows, b))
         V = torch.empty_like(A)
         T = torch.empty((nb, b, b), dtype=torch.float64, device="cuda")
-        W = A.clone()
+        Ws = [A.clone() for _ in range(nbf)]
 
         def go():
-            W.copy_(A)
-            _lib.check(h.lib.nd4hip_dgeqr2_panel_batched_dev(h.ptr, nb, rows, b, ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(V.data_ptr()),
-                                                             ctypes.c_void_p(T.data_ptr())))
+            for W in Ws:
+                _lib.check(h.lib.nd4hip_dgeqr2_panel_batched_dev(h.ptr, nb, rows, b, ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(V.data_ptr()),
+                                                                 ctypes.c_void_p(T.data_ptr())))
 
-        def only_copy():
-            W.copy_(A)
-        ms_all = _median_ms(go, h)[0]
-        ms_copy = _median_ms(only_copy, h)[0]
-        us = max(ms_all - ms_copy, 1e-6) * 1e3
+        def restore():                     # outside the timed region: a call overwrites (at least) the top block of its input with R
+            for W in Ws:
+                W.copy_(A)
+        us = _median_ms(go, h, reps=10, warm=2, prep=restore)[0] * 1e3 / nbf
         byts = 16.0 * rows * b * nb
         res[name] = {"panels": nb, "rows": rows, "us": round(us, 2), "bytes": byts, "GBps": round(byts / us / 1e3, 1),
                      "frac_hbm_peak": round(byts / us / 1e3 / PEAK_HBM_GBS, 4)}
+        del Ws, A, V, T
     return res

@@ -692,7 +692,9 @@ __device__ __forceinline__ void qrh_ge_all(double (&g)[16], double (&d)[16], std
 // One wave. s_G: symmetric positive definite 16 x 16. Out: s_R = chol(G)^T (upper, G = R^T R), s_Ri = R^-1 (upper).
 // Lanes 0..15 hold the columns of G, lanes 16..31 the columns of I; elimination without pivoting leaves U = D L^T and L^-1,
 // R = D^-1/2 U, R^-1 = (D^-1/2 L^-1)^T. Returns true when every pivot is positive and >= thr * its diagonal entry.
-__device__ __forceinline__ bool qrh_chol16(const double* __restrict__ s_G, double* __restrict__ s_R, double* __restrict__ s_Ri, double thr) {
+// Optional: s_Rt[j * 16 + i] = R[i][j] (column j contiguous) and s_rd[i] = 1 / R[i][i], what a forward substitution x R = c reads.
+__device__ __forceinline__ bool qrh_chol16(const double* __restrict__ s_G, double* __restrict__ s_R, double* __restrict__ s_Ri, double thr,
+                                           double* __restrict__ s_Rt = nullptr, double* __restrict__ s_rd = nullptr) {
   const int lane = threadIdx.x & 63;
   double g[16], d[16], d0[16];
 #pragma unroll
@@ -712,6 +714,12 @@ __device__ __forceinline__ bool qrh_chol16(const double* __restrict__ s_G, doubl
   if (lane < 16) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s_R[i * 16 + lane] = (i <= lane) ? g[i] * rs[i] : 0.0;
+    if (s_Rt != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) s_Rt[lane * 16 + i] = (i <= lane) ? g[i] * rs[i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) if (i == lane) s_rd[i] = rs[i];
+    }
   } else if (lane < 32) {
     const int c = lane - 16;
 #pragma unroll
@@ -2190,6 +2198,9 @@ __global__ __launch_bounds__(256) void qr_t_assemble(double* __restrict__ Tall, 
   Tall[so + t] = s_t[i][j];
 }
 
+#include "qr_chain16.h"
+#include "qr_batched_panel.h"
+
 template <int R, int NWV = 8>
 void launch_panel_row(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
                       double* T, long sT, double* taus, long sTau, int j0, int nb) {
@@ -2201,6 +2212,24 @@ void launch_panel_row(nd4hip_handle* h, int batch, double* W, int M, long ld, lo
 // and a column step is ~530 instructions of ONE wave) — 2048 panels of 512 rows: 220 -> 151 us, 4096 of 256 rows: 315 -> 154 us
 // (bench ops.qr_panel). All three shapes then run at the same 1.75 TB/s: the launch is bound by the instruction issue of the
 // 4096 wave-panels (8500 instructions each, two waves per SIMD); forcing three waves per SIMD spills (196 us).
+// Batches of full panels on the matrix cores (qr_batched_panel.h). ZERO: the rows below the top block are zeroed in W.
+template <int R, int NWV, bool ZERO>
+static void launch_qrb(nd4hip_handle* h, int batch, double* W, int M, long ld, long sW, double* V, long ldv, long sV,
+                       double* T, long sT, double* taus, long sTau, int j0, long long* stamps) {
+  hipLaunchKernelGGL((qrb_panel<R, NWV, ZERO>), dim3(batch), dim3(64 * NWV), 0, h->stream, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+}
+template <bool ZERO>
+static void launch_panel_mfma(nd4hip_handle* h, int batch, double* W, int M, int m, long ld, long sW, double* V, long ldv, long sV,
+                              double* T, long sT, double* taus, long sTau, int j0, long long* stamps = nullptr) {
+  static const int small_min = [] { const char* e = getenv("ND4HIP_QR_SMALL_WG_BATCH"); return e ? atoi(e) : 64; }();   // 0: never
+  const bool many = small_min > 0 && batch >= small_min;
+  if (many && m <= 256)       launch_qrb<4, 1, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+  else if (many && m <= 512)  launch_qrb<4, 2, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+  else if (many && m <= 1024) launch_qrb<4, 4, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+  else if (m <= 512)          launch_qrb<1, 8, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+  else if (m <= 1024)         launch_qrb<2, 8, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+  else                        launch_qrb<4, 8, ZERO>(h, batch, W, M, ld, sW, V, ldv, sV, T, sT, taus, sTau, j0, stamps);
+}
 static void launch_panel_rows(nd4hip_handle* h, int batch, double* W, int M, int m, long ld, long sW, double* V, long ldv, long sV,
                               double* T, long sT, double* taus, long sTau, int j0, int nb) {
   static const int small_min = [] { const char* e = getenv("ND4HIP_QR_SMALL_WG_BATCH"); return e ? atoi(e) : 64; }();   // 0: never
@@ -2831,6 +2860,26 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 1; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
     P.stamps = nullptr; P.stamp_slot = 0;
     ND4_TRY(hr.panel(0, NB, false, true));
+    return 0;
+  }
+  static const bool qrb_off = [] { const char* e = getenv("ND4HIP_QR_NO_BATCHED_MFMA"); return e && *e && *e != '0'; }();
+  if (!qrb_off && nb == NB && M >= HR_MIN_ROWS) {
+    // a batch of panels: one workgroup per panel on the matrix cores (qr_batched_panel.h); V = Q - [S; 0], T = K as above
+    static const bool stamps_on = [] { const char* e = getenv("ND4HIP_QRB_STAMPS"); return e && *e && *e != '0'; }();
+    long long* stamps = nullptr;
+    if (stamps_on) { static long long* dbuf = nullptr; if (!dbuf) ND4_HIP(hipMalloc(&dbuf, 512)); stamps = dbuf; }
+    launch_panel_mfma<false>(h, batch, A, M, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, stamps);
+    ND4_HIP(hipGetLastError());
+    if (stamps) {
+      long long hs[64];
+      static const char* names[13] = {"load+gram", "wait all", "chol", "barrier", "q1", "gram2", "wait all", "series", "barrier", "q", "gj", "stores", "T"};
+      ND4_HIP(hipStreamSynchronize(h->stream));
+      ND4_HIP(hipMemcpy(hs, stamps, 512, hipMemcpyDeviceToHost));
+      fprintf(stderr, "qrb stamps %d x %d rows (us | shader cycles; workgroup 0):", batch, M);
+      for (int k = 0; k < 13; k++) fprintf(stderr, " %s %.2f|%lld", names[k], (hs[2 * k + 2] - hs[2 * k]) * 0.01, hs[2 * k + 3] - hs[2 * k + 1]);
+      fprintf(stderr, " total %.2f|%lld; columns 4/8/12 of q1 at %lld %lld %lld of q at %lld %lld %lld\n", (hs[26] - hs[0]) * 0.01, hs[27] - hs[1],
+              hs[29] - hs[9], hs[31] - hs[9], hs[33] - hs[9], hs[35] - hs[19], hs[37] - hs[19], hs[39] - hs[19]);
+    }
     return 0;
   }
   launch_panel_rows(h, batch, A, M, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, nb);
