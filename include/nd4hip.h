@@ -32,6 +32,12 @@ typedef struct nd4hip_handle nd4hip_handle;
 #define ND4HIP_ERR_NOCONV   -3   /* Jacobi SVD hit the sweep limit */
 #define ND4HIP_ERR_NODEV    -4   /* no usable GPU */
 #define ND4HIP_ERR_SINGULAR -5   /* Cholesky met a NaN pivot: 'Matrix contains NaNs or is (near) singular.' */
+#define ND4HIP_ERR_XCHG     -6   /* an exchange between co-resident workgroups INSIDE a kernel timed out (the row-split QR panels, the
+                                    multi-workgroup LU panels): the results of the call are invalid — Q / R hold NaN, the permutation
+                                    vector of an LU holds -1 — and the handle stays usable. Reported by the next entry point that
+                                    synchronises: every host-pointer form, nd4hip_synchronize, nd4hip_timer_stop. The _dev forms
+                                    enqueue only and return 0; their callers see the NaN / -1 markers or the code at the next
+                                    nd4hip_synchronize. (The reference never returns a half-valid factorisation: lu.js:24-81.) */
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
 int  nd4hip_device_count(void);

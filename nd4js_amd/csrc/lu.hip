@@ -20,6 +20,7 @@
 //   lu_build_perm  P from the recorded interchanges, once per factorisation.
 #include "nd4hip_internal.h"
 #include "dpp.h"
+#include "xchg.h"
 #include <type_traits>
 #include <cfloat>
 
@@ -549,6 +550,7 @@ __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, dou
   }
   if (stage_top != nullptr && w == 0 && t < NB * NB) A[(long)(j0 - NB + t / NB) * N + j0 + t % NB] = stage_top[t];   // U12 of the previous panel for these columns
   if (prio) __builtin_amdgcn_s_setprio(3);          // the chain before the update workgroups that share the chip (and maybe the CU)
+  const int drop_tag = w == P - 1 ? stuck[1] : 0;    // tests only (ND4HIP_TEST_DROP_PUBLISH): the column whose publication this workgroup skips; 0 = none
   auto column = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int jc = j0 + k, tag = jc + 1;
@@ -594,7 +596,8 @@ __device__ __forceinline__ void lu_panel_mw_body(const int w, const int mat, dou
       int bi = c8.mag == bm ? c8.idx : 0x7fffffff;
       bi = min(bi, nd4dpp::xor1(bi)); bi = min(bi, nd4dpp::xor2(bi)); bi = min(bi, nd4dpp::xor4(bi));
       const int ww = (((bi - rbase) & (T - 1)) >> 6) & (NWV - 1);
-      if (lane < W) mw_st(myslot, lane, s_rows[ww][lane], (unsigned)tag);
+      if (drop_tag == tag) {}                                          // (tests: one dropped publication)
+      else if (lane < W) mw_st(myslot, lane, s_rows[ww][lane], (unsigned)tag);
       else if (lane == 16) mw_st(myslot, 16, bm, (unsigned)tag);
       else if (lane == 17) mw_st(myslot, 17, __longlong_as_double((long long)bi), (unsigned)tag);
       else if (w == 0 && lane >= 32 && lane < 32 + W) mw_st(myslot, 18 + (lane - 32), s_j[lane - 32], (unsigned)tag);
@@ -748,8 +751,9 @@ __global__ __launch_bounds__(512) void lu_panel_mw_la(double* __restrict__ LU, i
   }
   lu_update_block<512, true>((int)blockIdx.x - P, blockIdx.y, LU, N, strideM, pj0, wide0, ipiv, nopivot ? 0 : 1, Pm, full_end);
 }
-__global__ void lu_mw_poison(int32_t* __restrict__ P, long total, const int* __restrict__ stuck) {
+__global__ void lu_mw_poison(int32_t* __restrict__ P, long total, const int* __restrict__ stuck, int* __restrict__ status) {
   if (*stuck == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) qx_raise(status);          // -> ND4HIP_ERR_XCHG at the next synchronising entry point
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i < total) P[i] = -1;
 }
@@ -1032,6 +1036,11 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
     ND4_TRY(nd4_ws_alloc(h, xbytes, &xb));
     ND4_HIP(hipMemsetAsync(xb, 0, xbytes, h->stream));
     stuck = static_cast<int*>(xb);
+    if (const int dp = nd4_test_drop_panel(); dp >= 0) {               // tests only: word 1 = the column tag whose publication one workgroup drops
+      const int dtag = dp * NB + 1;
+      ND4_HIP(hipMemcpyAsync(stuck + 1, &dtag, sizeof(int), hipMemcpyHostToDevice, h->stream));
+      ND4_HIP(hipStreamSynchronize(h->stream));
+    }
     xbuf = reinterpret_cast<double*>(static_cast<char*>(xb) + 256);
   }
   // the part of an outer block's work beyond it: U12 = L11^-1 A12 for the whole block row, then ONE K = nbo product on the tiled MFMA kernel
@@ -1198,7 +1207,7 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   if (la_on && N - j_start <= 2048 && N - j_start >= 64 + NB) ND4_TRY(la_range(j_start, N, N, &j_start));
   // phase 3: what is left (short panels after the look-ahead form; everything when it is switched off), one level
   if (j_start < N) ND4_TRY(outer_block(j_start, N, false));
-  if (mw_on && p_in_laswp) hipLaunchKernelGGL(lu_mw_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, stuck);
+  if (mw_on && p_in_laswp) hipLaunchKernelGGL(lu_mw_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, stuck, h->xstat);
   if (p_in_laswp) { ND4_HIP(hipGetLastError()); return 0; }
   if ((size_t)N * sizeof(int32_t) <= 60 * 1024)
     hipLaunchKernelGGL(lu_build_perm, dim3((unsigned)batch), dim3(256), (size_t)N * sizeof(int32_t), h->stream, P, ipiv, N, nopivot);

@@ -1,6 +1,7 @@
 // libnd4hip.so core: handle lifecycle, error reporting, memory, timing, synthetic-input fill and the
 // small copy / transpose / identity kernels shared by the decompositions.
 #include "nd4hip_internal.h"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -42,6 +43,8 @@ extern "C" int nd4hip_create(nd4hip_handle** out, int device) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_p0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_p1);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->xstat), 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) *h->xstat = 0;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_aux_a, hipEventDisableTiming);
@@ -72,6 +75,7 @@ extern "C" void nd4hip_destroy(nd4hip_handle* h) {
   for (auto& b : h->ws) (void)hipFree(b.p);
   for (auto& b : h->stage) (void)hipFree(b.p);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->xstat) (void)hipHostFree(h->xstat);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_order) (void)hipEventDestroy(h->ev_order);
@@ -110,7 +114,19 @@ extern "C" int nd4hip_synchronize(nd4hip_handle* h) {
   ND4_CHECK_ARG(h != nullptr, "nd4hip_synchronize: NULL handle");
   Nd4DeviceGuard guard(h);
   ND4_HIP(hipStreamSynchronize(h->stream));
-  return 0;
+  return nd4_xchg_check(h, "nd4hip_synchronize");
+}
+
+int nd4_xchg_check(nd4hip_handle* h, const char* where) {
+  if (h->xstat == nullptr || *static_cast<volatile int*>(h->xstat) == 0) return 0;
+  *static_cast<volatile int*>(h->xstat) = 0;
+  nd4_set_error("%s: an exchange between workgroups inside a kernel timed out; the results of the calls since the last "
+                "synchronisation are invalid (NaN in Q / R, -1 in the permutation vector of an LU)", where);
+  return ND4HIP_ERR_XCHG;
+}
+int nd4_test_drop_panel() {
+  const char* e = getenv("ND4HIP_TEST_DROP_PUBLISH");
+  return (e && *e) ? atoi(e) : -1;
 }
 
 int nd4_ws_alloc(nd4hip_handle* h, size_t bytes, void** out) {
@@ -243,7 +259,7 @@ extern "C" int nd4hip_timer_stop(nd4hip_handle* h, float* ms) {
   ND4_HIP(hipEventRecord(h->ev1, h->stream));
   ND4_HIP(hipEventSynchronize(h->ev1));
   ND4_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
-  return 0;
+  return nd4_xchg_check(h, "nd4hip_timer_stop");
 }
 
 // ---------------------------------------------------------------- synthetic inputs

@@ -171,6 +171,7 @@ int run_block(nd4hip_handle* h, int dev, int64_t lo, int64_t hi, const std::vect
   if (rc != 0) return fail(rc);
   BLK_HIP(hipStreamSynchronize(cs));
   BLK_HIP(hipStreamSynchronize(h->stream));
+  BLK_TRY(nd4_xchg_check(h, "host-pointer entry point"));
 #undef BLK_TRY
 #undef BLK_HIP
   return 0;

@@ -27,6 +27,7 @@ struct nd4hip_handle {
   hipEvent_t ev_aux_a = nullptr, ev_aux_b = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_chunk[2] = {nullptr, nullptr};   // per staging set: inputs landed / kernels done
   std::vector<nd4hip_handle*> peers;  // further devices of a multi-device handle (nd4hip_create_multi); owned
+  int* xstat = nullptr;               // host-coherent status word the kernels raise when an in-kernel exchange times out (ND4HIP_ERR_XCHG)
   int num_cu = 256;
   unsigned ws_generation = 0;         // bumped whenever the idle arena is dropped and rebuilt (Nd4WsScope)
   int svd_sweeps = 0; unsigned long long svd_rotations = 0; double svd_offnorm = 0.0;   // audit of the last SVD call
@@ -57,6 +58,10 @@ struct Nd4Prof {
 };
 
 void nd4_set_error(const char* fmt, ...);
+// after a synchronisation: ND4HIP_ERR_XCHG (and the word cleared) if a kernel raised the handle's exchange status word
+int  nd4_xchg_check(nd4hip_handle* h, const char* where);
+// tests only: ND4HIP_TEST_DROP_PUBLISH=<panel> (read per call) makes one workgroup of that panel skip one publication
+int  nd4_test_drop_panel();
 int  nd4_hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define ND4_HIP(expr)                                                           \

@@ -672,6 +672,8 @@ struct QrhP {
   unsigned long long* Xsx; long strideXsx;   // fused side work: [column block][row chunk] slots of 512 tagged words (rcs_max chunks per block)
   int rcs_max;
   long long* stamps; int stamp_slot; // debug (ND4HIP_QR_STAMPS): 100 MHz wall-clock stamps of workgroup 0, 8 per launch
+  int* status;                      // the handle's exchange status word (host-coherent): raised when a spin limit is hit
+  int drop_tag;                     // tests only (ND4HIP_TEST_DROP_PUBLISH): the last row workgroup of the panel with this tag skips its first publication
 };
 
 template <int K, int I>
@@ -1002,7 +1004,7 @@ __device__ __forceinline__ void qrh_side_fused(const QrhP& P, int mat, int e, do
         bool ok = true;
         x = qx_sum(base, en, P.nrc, tag, ok);
         if (ok) break;
-        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }    // a stuck exchange must not pass silently
+        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); qx_raise(P.status); break; }    // a stuck exchange must not pass silently
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -1567,7 +1569,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
       double xs = 0.0;
 #pragma unroll
       for (int w = 0; w < 8; w++) xs += s_buf[w * 256 + t];
-      qx_st(myslot, t, xs, tag);
+      if (!(P.drop_tag == (int)tag && g == P.nrow - 1)) qx_st(myslot, t, xs, tag);   // (tests: one dropped publication)
     }
     __syncthreads();
 #pragma unroll
@@ -1592,7 +1594,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
         ok = ok && (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag;
         top = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
         if (ok) break;
-        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }    // a stuck exchange must not pass silently
+        if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); qx_raise(P.status); break; }    // a stuck exchange must not pass silently
         __builtin_amdgcn_s_sleep(2);
       }
       s_G[t] = x + top;
@@ -1662,7 +1664,8 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
             for (;;) {
               bool ok = true;
               (void)qx_sum(slots + (long)t * QX_ROW_SLOT, 768, 1, tag, ok, QX_ROW_SLOT);
-              if (ok || ++spins > QX_SPIN_LIMIT) break;
+              if (ok) break;
+              if (++spins > QX_SPIN_LIMIT) { qx_raise(P.status); break; }
               __builtin_amdgcn_s_sleep(4);
             }
           }
@@ -1722,7 +1725,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
       bool ok = true;
       x = qx_sum(slots, 1024 + t, P.nrow, tag, ok, QX_ROW_SLOT);
       if (ok) break;
-      if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); break; }      // a stuck exchange must not pass silently
+      if (++spins > QX_SPIN_LIMIT) { x = __builtin_nan(""); qx_raise(P.status); break; }      // a stuck exchange must not pass silently
       __builtin_amdgcn_s_sleep(2);
     }
     x -= (i == j) ? 1.0 : 0.0;                                         // E = Q1^T Q1 - I
@@ -2586,7 +2589,7 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     ND4_HIP(hipMemsetAsync(hrFlag, 0, sizeof(int) * (size_t)batch, h->stream));
     P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 0; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
     static const bool want_stamps = [] { const char* e = getenv("ND4HIP_QR_STAMPS"); return e && *e && *e != '0'; }();
-    P.stamps = nullptr; P.stamp_slot = 0;
+    P.stamps = nullptr; P.stamp_slot = 0; P.status = h->xstat; { const int dp = nd4_test_drop_panel(); P.drop_tag = dp >= 0 ? dp + 1 : -1; }
     if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
   }
   if (lookahead) {
@@ -2773,8 +2776,15 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
         ND4_HIP(hipGetLastError());
       }
     } else
-    if (m <= 2048)      launch_panel_rows(h, batch, W, M, m, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
-    else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    if (m <= 2048) {
+      // batches of full panels: one workgroup per panel on the matrix cores (qr_batched_panel.h: V = Q - [S; 0], full T, like the
+      // row-split panels of one matrix); short / narrow / odd-stride panels keep the thread-per-row Householder kernel
+      static const bool qrb_off = [] { const char* e = getenv("ND4HIP_QR_NO_BATCHED_MFMA"); return e && *e && *e != '0'; }();
+      if (!qrb_off && batch > 8 && nb == NB && m >= HR_MIN_ROWS && (ld & 1) == 0 && (ws.ldv & 1) == 0)
+        launch_panel_mfma<true>(h, batch, W, M, m, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0);
+      else
+        launch_panel_rows(h, batch, W, M, m, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
+    } else                launch_panel<1, false>(h, batch, W, M, ld, sW, ws.V, ws.ldv, ws.sV, ws.T, ws.sT, ws.taus, ws.sTau, j0, nb);
     ND4_HIP(hipGetLastError());
     // trailing columns of the outer block: C <- H^T C = (I - V T^T V^T) C
     ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + nb, ld, sW, bend - j0 - nb));
@@ -2856,9 +2866,10 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     ND4_HIP(hipMemsetAsync(P.G2p, 0, sizeof(double) * (size_t)batch * P.strideG2, h->stream));
     P.R1 = d; d += (size_t)batch * 256;
     P.flag = reinterpret_cast<int*>(d);
+    ND4_HIP(hipMemsetAsync(P.flag, 0, sizeof(int) * (size_t)batch, h->stream));   // (as in the main path: never read before written today, but not by accident)
     P.QT = nullptr; P.strideQT = 0; P.nxp = 0; P.Xs = nullptr; P.strideXs = 0;
     P.nseg = 0; P.wide0 = 0; P.nrc = 1; P.nnw = 0; P.nqb = 0; P.skip_x = 1; P.j0 = 0; P.pj0 = -1; P.nrow = 0; P.ngp = 0;
-    P.stamps = nullptr; P.stamp_slot = 0;
+    P.stamps = nullptr; P.stamp_slot = 0; P.status = h->xstat; { const int dp = nd4_test_drop_panel(); P.drop_tag = dp >= 0 ? dp + 1 : -1; }
     ND4_TRY(hr.panel(0, NB, false, true));
     return 0;
   }

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void jac_small(double* __restrict__ Wm, double
   bool converged = N <= 1;
   unsigned my_rot = 0; double my_off = 0.0;
   while (!converged && sweeps < max_sweeps) {
+    if (t == 0) s_off = 0;                                          // only the LAST sweep's rotations count (the rounds' barriers order this)
     for (int step = 0; step < n2 - 1; step++) {
       const unsigned pq = s_pair[step * 32 + pr];
       const int p = pq & 255, q = pq >> 8;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void jac_small(double* __restrict__ Wm, double
     }
     sweeps++;
     if (sub == 0 && my_rot) { atomicAdd(&s_rot, my_rot); atomicMax(&s_off, (unsigned long long)__double_as_longlong(my_off)); }
-    my_rot = 0;
+    my_rot = 0; my_off = 0.0;
     __syncthreads();
     const unsigned r = s_rot;
     __syncthreads();

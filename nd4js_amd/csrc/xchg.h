@@ -7,8 +7,16 @@
 #include <hip/hip_runtime.h>
 
 typedef unsigned long long qx_u64;
-constexpr int QX_SPIN_LIMIT = 1 << 20;      // polls of ~1 us: a stuck exchange ends after about a second (with garbage; cannot happen
-                                            // while the partners are co-resident or next in the dispatch order)
+// The partners of an exchange are consecutive workgroups of ONE launch and the host only uses it while they all fit on the chip at
+// once (QR: the row workgroups of a panel launch come first in the grid, at most 8 x 33 of 512 threads = one per CU; LU:
+// P x batch <= 64 workgroups), so each partner is resident or next in the dispatch order. HIP does not promise that order, and a GPU
+// shared with other processes may delay a workgroup: every spin is therefore bounded. A stuck exchange ends after about a second
+// (QX_SPIN_LIMIT polls of ~1 us), marks its results (NaN / P = -1) and raises the handle's status word, which the next synchronising
+// entry point turns into ND4HIP_ERR_XCHG.
+constexpr int QX_SPIN_LIMIT = 1 << 20;
+__device__ __forceinline__ void qx_raise(int* status) {
+  if (status != nullptr) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void qx_st(qx_u64* slot, int v, double x, unsigned tag) {
   const qx_u64 bits = (qx_u64)__double_as_longlong(x), tg = (qx_u64)tag << 32;
