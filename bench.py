@@ -57,8 +57,8 @@ def cpu_baseline_matmul(n, rows):
 
 
 def cpu_baseline_ops(n=2048):
-    """The oracle (C port, 1 core, same flop conventions) beside every side op: LU and QR of the full 2048^2 config once each,
-    two-sided Jacobi SVD (svd_jac_2sided.js) at 512^2 (the 2048^2 run would take minutes)."""
+    """The oracle (C port, 1 core, same flop conventions) beside every side op: LU, QR and svd_decomp of the full 2048^2 config once
+    each, svd_decomp at 512^2."""
     import oracle
     from nd4js_amd import rng
     out = {}
@@ -73,38 +73,68 @@ def cpu_baseline_ops(n=2048):
     dt = time.perf_counter() - t
     out["qr%d" % n] = {"seconds": round(dt, 3), "gflops": round(8.0 / 3.0 * n ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
                        "reference_js_survey_s": REFERENCE_JS_SURVEY_S.get("qr%d" % n)}
+    # svd_decomp: the reference's OWN algorithm (svd_dc: bidiagonalisation + divide & conquer, svd_dc.js:883-932, restated in
+    # oracle/nd4_oracle_svd_dc.c and pinned to the reference's goldens) on 1 core: member 0 of the 1024 x 512^2 batch, and the
+    # 2048^2 config itself (~30 s; ND4_BENCH_CPU_SVD2048=0 skips it)
     m = 512
     x = rng.matrix(1000, m, m)
     t = time.perf_counter()
-    _, sv, _, sweeps = oracle.svd_jac_2sided(x)
+    _, sv, _ = oracle.svd_dc(x)
     dt = time.perf_counter() - t
-    out["svd%d" % m] = {"seconds": round(dt, 3), "gflops_nominal": round(21.0 * m ** 3 / dt / 1e9, 3), "cores": 1,
-                        "kind": "port of a DIFFERENT algorithm",
-                        "algorithm": "two-sided Jacobi (svd_jac_2sided.js:95-134), %d sweeps — NOT the reference's svd_decomp (= svd_dc, "
-                                     "bidiagonalisation + divide & conquer, svd_dc.js:883-932), which the oracle does not restate" % sweeps,
+    out["svd%d" % m] = {"seconds": round(dt, 3), "gflops_nominal": round(21.0 * m ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
+                        "algorithm": "svd_dc (bidiagonalisation + divide & conquer), the reference's svd_decomp",
                         "reference_js_survey_s": REFERENCE_JS_SURVEY_S["svd512"],
-                        "baseline_for_speedups": "the reference's own svd_decomp timed in the survey container (1 thread): %.3f s at 512^2, %.1f s at "
-                                                 "2048^2 — this Jacobi port is ~4x slower than that and must not be used as the speed-up baseline"
-                                                 % (REFERENCE_JS_SURVEY_S["svd512"], REFERENCE_JS_SURVEY_S["svd2048"]),
-                        "note": "sample for the 2048^2 and the 1024 x 512^2 configs: matrix 0 of the batch"}
+                        "note": "sample for the 1024 x 512^2 config: matrix 0 of the batch"}
+    if os.environ.get("ND4_BENCH_CPU_SVD2048", "1") != "0":
+        x2 = rng.matrix(9, n, n)
+        t = time.perf_counter()
+        _, sv2, _ = oracle.svd_dc(x2)
+        dt = time.perf_counter() - t
+        out["svd%d" % n] = {"seconds": round(dt, 3), "gflops_nominal": round(21.0 * n ** 3 / dt / 1e9, 3), "cores": 1, "kind": "port",
+                            "algorithm": "svd_dc (bidiagonalisation + divide & conquer), the reference's svd_decomp",
+                            "reference_js_survey_s": REFERENCE_JS_SURVEY_S.get("svd%d" % n), "sv_max": float(sv2[0])}
     return out, (p, r, sv)
 
 
-def cpu_baseline_svd_batch(count=16):
+def cpu_baseline_svd_batch(count=64):
     """BASELINE configs[4] on ALL host cores: `count` members of the 1024 x 512^2 batch spread over the cores this
-    process may use (at most 16: the GPU box's CPU share per GPU), in a child process (no fork after the GPU is initialised)."""
+    process may use (at most 16: the GPU box's CPU share per GPU), in a child process (no fork after the GPU is initialised);
+    the reference's own algorithm (svd_dc) as restated in oracle/nd4_oracle_svd_dc.c."""
     import subprocess
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, min(avail, 16, count))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_batch.py"), "--count", str(count), "--workers", str(workers), "--n", "512"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_batch.py"), "--count", str(count), "--workers", str(workers), "--n", "512",
+                        "--algo", "dc"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     if r.returncode != 0:
         return {"error": r.stderr[-400:]}
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    d.update({"kind": "port of a DIFFERENT algorithm", "algorithm": "two-sided Jacobi (see ops.svd512)", "cores": d["workers"],
-              "sample": "%d members (seeds 1000..) of the 1024 x 512^2 batch, one per process" % d["count"],
+    d.update({"kind": "port", "algorithm": "svd_dc (the reference's svd_decomp)", "cores": d["workers"],
+              "sample": "%d members (seeds 1000..) of the 1024 x 512^2 batch, spread over %d processes" % (d["count"], d["workers"]),
               "batch1024_extrapolated_s": round(1024.0 / d["matrices_per_s"], 1),
               "reference_js_survey_batch1024_1core_s": round(1024 * REFERENCE_JS_SURVEY_S["svd512"], 0)})
+    return d
+
+
+def node_leg(n=4096, svd_batch=1024):
+    """The production boundary (the Node.js host over the N-API addon, matmul.js:91-147 reached through
+    nd4js_amd/js): 4096^2 matmul2 and a batch of 512^2 SVDs from host Float64Arrays and from DeviceNDArrays, timed by
+    tools/node_bench.js in a child process. Skipped when node or the addon is absent."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "nd4js_amd", "js", "nd4hip_napi.node")
+    if not node or not os.path.exists(addon):
+        return {"skipped": "node or the N-API addon is not available on this box"}
+    try:
+        r = subprocess.run([node, os.path.join(ROOT, "tools", "node_bench.js"), str(n), str(svd_batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=300)
+    except Exception as ex:  # pragma: no cover
+        return {"error": repr(ex)}
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d["what"] = ("through nd4js_amd/js (N-API): host_* = Float64Array operands and results (PCIe both ways per call), device_* = DeviceNDArray "
+                 "operands and results; best of 2-5 wall-clock timings inside node")
     return d
 
 
@@ -250,7 +280,8 @@ def main():
                 # that cannot bend; this block is the batched-SVD scaling point of this run (strong scaling: fixed batch)
                 out["scale"] = {"workload": "batch of %d x (%dx%d) fp64 SVDs sharded over %d GPUs (BASELINE configs[4])" % (sb["batch"], sb["n"], sb["n"], world),
                                 "scaling": "strong", "n_gpus": world, "kernel_only": sb.get("kernel_only"), "end_to_end": sb.get("end_to_end"),
-                                "max_sweeps": sb.get("max_sweeps")}
+                                "max_sweeps": sb.get("max_sweeps"),
+                                "lu_batch": ops.get("lu_batch"), "qr_batch": ops.get("qr_batch")}     # the same batch shape through lu_decomp / qr_decomp
             if "sv_vs_reference_max_rel" in sb:
                 gates["svd_batch_sv_vs_reference_max_rel"] = (sb["sv_vs_reference_max_rel"], 1e-10)
             # (the off-norm of a converged Jacobi run is <= N eps by construction: reported, not a gate)
@@ -276,12 +307,14 @@ def main():
                     gates["svd2048_orth_U_max"] = (ck["orth_U_max"], ck["orth_limit"])
                     gates["svd2048_orth_V_max"] = (ck["orth_V_max"], ck["orth_limit"])
                     gates["svd2048_sv_unsorted_or_negative"] = (0.0 if ck["sv_sorted_nonnegative"] else 1.0, 0.0)
+            if world == 1 and os.environ.get("ND4_BENCH_NODE", "1") != "0":
+                ops["node"] = node_leg(4096, int(os.environ.get("ND4_BENCH_NODE_SVD_BATCH", "1024")))
             if world == 1 and not args.no_cpu_baseline:
                 # the CPU port beside every side op, and its results as one more parity check of the device results
                 cpu_ops, (p_cpu, r_cpu, sv_cpu) = cpu_baseline_ops(2048)
                 out["cpu_baseline"]["ops"] = cpu_ops
                 try:
-                    cpu_ops["svd_batch_all_cores"] = cpu_baseline_svd_batch(16)
+                    cpu_ops["svd_batch_all_cores"] = cpu_baseline_svd_batch(64)
                 except Exception as ex:  # pragma: no cover
                     cpu_ops["svd_batch_all_cores"] = {"error": repr(ex)}
                 from nd4js_amd import dev

@@ -21,12 +21,12 @@ EPS = 2.220446049250313e-16
 
 def _median_ms(fn, h, reps=10, warm=2, prep=None):
     """prep (optional) runs before every call, outside the timed region (e.g. restoring an operand that fn overwrites)."""
+    h.set_stream(torch.cuda.current_stream().cuda_stream)   # (before the warm-ups: a change of stream re-orders the workspace arena once)
     for _ in range(warm):                  # workspace allocation, code load, clocks back up after an idle phase
         if prep is not None:
             prep()
         fn()
     torch.cuda.synchronize()
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
     ms = []
     for _ in range(reps):
         if prep is not None:
@@ -34,6 +34,7 @@ def _median_ms(fn, h, reps=10, warm=2, prep=None):
         h.timer_start()
         fn()
         ms.append(h.timer_stop())
+    _median_ms.last = [round(x, 3) for x in ms]      # every iteration of the last measurement (a lazy first iteration shows here)
     return statistics.median(ms), min(ms), max(ms)
 
 
@@ -115,7 +116,7 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
         while time.perf_counter() - t_spin < 0.2:
             dev.matmul2(A, A)
             torch.cuda.synchronize()
-        out["lu%d" % N] = _entry(_median_ms(lambda: dev.lu_decomp(A), h), 2.0 / 3.0 * N ** 3)
+        out["lu%d" % N] = _entry(_median_ms(lambda: dev.lu_decomp(A), h, warm=3), 2.0 / 3.0 * N ** 3, ms_each=list(_median_ms.last))
         out["qr%d" % N] = _entry(_median_ms(lambda: dev.qr_decomp(A), h), 8.0 / 3.0 * N ** 3)
         # beyond the register-resident panels (N > 2048: two-level blocking; the reference author's own benchmark range ends at
         # N ~ 3100, benchmarks/bench_la_decomps.html:285-288): same flop conventions, median of 5
@@ -135,6 +136,19 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
         S = dev.gemm_ex(False, True, 1.0, A, A, 0.0, torch.empty_like(A), N, N, N, N, N, N)
         S.diagonal().add_(float(N))
         out["cholesky%d" % N] = _entry(_median_ms(lambda: dev.cholesky_decomp(S), h), N ** 3 / 3.0)
+        # the remaining built rows under the same clock: LDL^T (N^3/3), Hessenberg reduction with U
+        # (10/3 N^3 + 4/3 N^3), bidiagonalisation with U and V (8/3 N^3 + 2 x 4/3 N^3), least squares on device-resident factors with
+        # N right-hand sides (qr_lstsq: Q^T Y + back substitution = 3 N^3; svd_lstsq: two products = 4 N^3); median of 5
+        Sl = S.clone()
+        Sl.diagonal().sub_(2.0 * float(N))                  # indefinite (LDL^T does not need definiteness), still diagonally dominant
+        out["ldl%d" % N] = _entry(_median_ms(lambda: dev.ldl_decomp(Sl), h, reps=5, warm=1), N ** 3 / 3.0)
+        out["hess%d" % N] = _entry(_median_ms(lambda: dev.hessenberg_decomp(A), h, reps=5, warm=1), 14.0 / 3.0 * N ** 3)
+        out["bidiag%d" % N] = _entry(_median_ms(lambda: dev.bidiag_decomp(A), h, reps=5, warm=1), 16.0 / 3.0 * N ** 3)
+        Qd, Rd = dev.qr_decomp(A)
+        out["qr_lstsq%d" % N] = _entry(_median_ms(lambda: dev.qr_lstsq(Qd, Rd, Y), h, reps=5, warm=1), 3.0 * N ** 3, rhs_columns=N)
+        for k in ("ldl%d" % N, "hess%d" % N, "bidiag%d" % N, "qr_lstsq%d" % N):
+            out[k]["timing"] = "median of 5 (HIP events)"
+        del Sl, Qd, Rd
         A9 = dev.fill_uniform(9, (N, N))
         info = {}
         ms3 = _median_ms(lambda: dev.svd_decomp(A9, info=info), h, reps=10, warm=1)
@@ -142,6 +156,10 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
         e.update({"ms_min": round(ms3[1], 2), "ms_max": round(ms3[2], 2), "timing": "median of 10 (HIP events)"})
         e["checks"] = svd_checks(dev, A9, N)
         out["svd%d" % N] = e
+        U9, s9, V9 = dev.svd_decomp(A9)
+        out["svd_lstsq%d" % N] = _entry(_median_ms(lambda: dev.svd_lstsq(U9, s9, V9, Y), h, reps=5, warm=1), 4.0 * N ** 3, rhs_columns=N)
+        out["svd_lstsq%d" % N]["timing"] = "median of 5 (HIP events)"
+        del U9, s9, V9
         # small problems (VERDICT r2 #7a): all sweeps of an N <= 64 matrix in ONE launch (jac_small), device-resident
         try:
             S1 = dev.fill_uniform(31, (32, 32))
@@ -160,11 +178,17 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
             out["qr_panel"] = qr_panel(h, dev)
         except Exception as ex:  # pragma: no cover
             out["qr_panel"] = {"error": repr(ex)}
-    # ---- batched SVD, batch axis sharded over ranks ----
+    # ---- batched LU / QR (1024 x 512^2, the shapes of BASELINE configs[4]), batch axis sharded over ranks like the SVD below:
+    #      the regime in which the chip is filled (qr.js:43-49, lu.js:34-40 loop over independent matrices) ----
     B = int(os.environ.get("ND4_BENCH_SVD_BATCH", svd_batch or 1024))
     n = 512
     lo, hi = shard(B, world, rank)
     mine = hi - lo
+    for name, fn, fl, by in (("lu_batch", dev.lu_decomp, 2.0 / 3.0 * n ** 3, 16.0 * n * n), ("qr_batch", dev.qr_decomp, 8.0 / 3.0 * n ** 3, 24.0 * n * n)):
+        try:
+            out[name] = batch_decomp(h, dev, dist, world, rank, name, fn, B, n, lo, hi, fl, by)
+        except Exception as ex:  # pragma: no cover
+            out[name] = {"error": repr(ex)}
     X = torch.empty((mine, n, n), dtype=torch.float64, device="cuda")
     for k in range(mine):
         _lib.check(h.lib.nd4hip_fill_uniform_dev(h.ptr, 1000 + lo + k, 0, n * n, X[k].data_ptr()))
@@ -250,6 +274,44 @@ def run(world, rank, local, dist, svd_batch=None, n_single=2048, end_to_end=True
             res["parity_error"] = repr(e)
     out["svd_batch"] = res
     return out
+
+
+def batch_decomp(h, dev, dist, world, rank, name, fn, B, n, lo, hi, flops_each, bytes_each, reps=5):
+    """`B` independent n x n factorisations, this rank's contiguous block [lo, hi) device-resident, no collective on the data path;
+    per repetition: barrier + synchronize on both sides, the MAX over ranks of the wall time; median of `reps`."""
+    from nd4js_amd import _lib
+    mine = hi - lo
+    X = torch.empty((mine, n, n), dtype=torch.float64, device="cuda")
+    for k in range(mine):
+        _lib.check(h.lib.nd4hip_fill_uniform_dev(h.ptr, 3000 + lo + k, 0, n * n, X[k].data_ptr()))
+    nccl = dist is not None and dist.get_backend() == "nccl"
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fn(X[: min(mine, 8)])
+    fn(X)
+    times = []
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        fn(X)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if nccl else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        times.append(dt)
+    dt = statistics.median(times)
+    return {"batch": B, "n": n, "n_gpus": world, "matrices_per_rank": mine, "seconds": round(dt, 5), "matrices_per_s": round(B / dt, 1),
+            "gflops": round(flops_each * B / dt / 1e9, 1), "frac_mfma_peak": round(flops_each * B / dt / 1e12 / PEAK_FP64_TFLOPS / world, 4),
+            "algorithmic_bytes": bytes_each * B, "GBps": round(bytes_each * B / dt / 1e9, 1),
+            "frac_hbm_peak": round(bytes_each * B / dt / 1e9 / PEAK_HBM_GBS / world, 4),
+            "timing": "median of %d (wall clock, barrier + synchronize on both sides, max over ranks), device-resident" % reps,
+            "scaling": "strong (fixed batch sharded over ranks)"}
 
 
 def qr_panel(h, dev, M=2048, b=16, batch=256, nbuf=8):

@@ -20,7 +20,7 @@ _i64 = ctypes.c_int64
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("nd4_oracle.c", "nd4_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("nd4_oracle.c", "nd4_oracle_svd_dc.c", "nd4_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _SO
@@ -57,6 +57,8 @@ def lib():
         L.nd4o_qr_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp]
         L.nd4o_svd_lstsq.argtypes = [_i64] * 5 + [_dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _dp]
         L.nd4o_svd_lstsq.restype = ctypes.c_int
+        L.nd4o_svd_dc.restype = ctypes.c_int
+        L.nd4o_svd_dc.argtypes = [_i64, _i64, _i64, _dp, _dp, _dp, _dp]
         L.nd4o_svd_jac_2sided.restype = ctypes.c_int
         L.nd4o_svd_jac_2sided.argtypes = [_i64, _i64, _dp, _dp, _dp, _dp]
         _lib = L
@@ -133,6 +135,25 @@ def lu_decomp(a):
     p = np.empty(a.shape[:-1], dtype=np.int32)
     lib().nd4o_lu_decomp(batch, N, _d(a), _d(lu), _i(p))
     return lu, p
+
+
+def svd_dc(a):
+    """nd.la.svd_decomp = svd_dc (svd_dc.js:883-932): bidiagonalisation + divide & conquer, any M x N, leading batch dims."""
+    a = _f64(a)
+    M, N = a.shape[-2:]
+    L = min(M, N)
+    lead = a.shape[:-2]
+    batch = int(np.prod(lead, dtype=np.int64))
+    u = np.empty(lead + (M, L))
+    sv = np.empty(lead + (L,))
+    v = np.empty(lead + (L, N))
+    rc = lib().nd4o_svd_dc(batch, M, N, _d(a), _d(u), _d(sv), _d(v))
+    if rc != 0:
+        raise RuntimeError("svd_dc: 'Assertion failed.' (svd_dc.js:%d)" % rc if rc > 0 else "svd_dc: out of memory")
+    return u, sv, v
+
+
+svd_decomp = svd_dc          # svd.js:25
 
 
 def svd_jac_2sided(a):

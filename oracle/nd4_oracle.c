@@ -685,3 +685,6 @@ int nd4o_svd_jac_2sided(int64_t batch, int64_t N, const double* A, double* U, do
   free(S); free(ord);
   return sweeps_max;
 }
+
+/* ------------------------------------------------------------------ svd_decomp = svd_dc (bidiagonalisation + divide & conquer) */
+#include "nd4_oracle_svd_dc.c"

@@ -86,6 +86,11 @@ int nd4o_svd_lstsq(int64_t batch, int64_t N, int64_t M, int64_t I, int64_t J, co
  * U[batch,N,N], sv[batch,N], V[batch,N,N] (rows of V = right singular vectors). Returns sweeps. */
 int nd4o_svd_jac_2sided(int64_t batch, int64_t N, const double* A, double* U, double* sv, double* V);
 
+/* src/la/svd_dc.js:883-932 svd_dc (= nd.la.svd_decomp, svd.js:25; kernels :37-880 + bidiag.js:164-242), restated in
+ * nd4_oracle_svd_dc.c: A [batch,M,N] -> U [batch,M,L], sv [batch,L], V [batch,L,N], L = min(M,N). Returns 0, the line number of
+ * the reference assertion that failed, or -1 (out of memory). */
+int nd4o_svd_dc(int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* sv, double* V);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,32 @@ def test_svd_jac_2sided_matches_reference(golden, name):
     assert np.abs(v @ np.swapaxes(v, -1, -2) - eye).max() <= 4 * eps * N
 
 
+@pytest.mark.parametrize("name", [c for c in golden_cases(op="svd_decomp") if not c.startswith(("c4_", "c5_"))])
+def test_svd_dc_matches_reference(golden, name):
+    """oracle/nd4_oracle_svd_dc.c restates the reference's svd_decomp (= svd_dc, svd_dc.js:37-932: bidiagonalisation + divide &
+    conquer) statement by statement; against the reference's own U, sv, V on square, wide, tall, batched and edge-family inputs.
+    Bit-identical wherever the 2 x 3 base case's atan2 / sin / cos agree between V8 and libm (c1_svd32, wide, diagonal, 1 x 1);
+    elsewhere 1e-13 — including the SIGNS of every singular vector (nothing is re-normalised)."""
+    g = golden(name)
+    a = make_input(g.seed, g.shape, g.family)
+    u, sv, v = oracle.svd_dc(a)
+    smax = max(g["sv"].max(), 1e-300)
+    assert u.shape == g["U"].shape and v.shape == g["V"].shape
+    assert np.abs(sv - g["sv"]).max() <= 1e-13 * smax
+    assert np.abs(u - g["U"]).max() <= 1e-13 and np.abs(v - g["V"]).max() <= 1e-13
+
+
+def test_svd_dc_c5_members(golden):
+    """Members 0, 16, 32 of BASELINE configs[4] (512 x 512, seeds 1000 + b) against the reference's singular values."""
+    from nd4js_amd import rng
+    g = golden("c5_svd512")
+    members, ref = g["members"], g["sv"]
+    for k in range(3):
+        a = rng.matrix(g.seed_base + int(members[k]), 512, 512)
+        _, sv, _ = oracle.svd_dc(a)
+        assert np.abs(sv - ref[k]).max() <= 1e-12 * ref[k].max()
+
+
 @pytest.mark.parametrize("name", [c for c in golden_cases(op="svd_decomp") if c.startswith(("c1_", "mid_svd96", "b_svd", "edge_svd_"))])
 def test_jacobi_sv_equal_svd_decomp_sv(golden, name):
     """The oracle's Jacobi sv must equal the sv of svd_decomp (= svd_dc, the public function)."""
