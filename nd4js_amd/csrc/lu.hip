@@ -1019,7 +1019,13 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   // swap), then U12 = L11^-1 A12 for the whole block row (unit lower, the one-launch solver of trsm.hip on a contiguous
   // copy) and ONE K = 256 product A22 -= L21 U12 on the tiled MFMA kernel. N <= 2048: one level (nbo = N), as before.
   static const int nbo_env = [] { const char* e = getenv("ND4HIP_LU_OUTER"); return e ? atoi(e) : 512; }();
-  const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : N;
+  // Batches that fill the chip (no look-ahead form, see la_on below) are bound by the read-modify-write of every trailing matrix per
+  // 16-column panel (1024 x 512^2: 45 GB for 4.3 GB of matrices): two levels for them too, outer blocks of ND4HIP_LU_BATCH_OUTER
+  // columns (1024 x 512^2: one level 19.9 ms, outer 32 / 64 / 128: 16.6 / 15.8 / 14.7 ms).
+  static const int la_max_batch = [] { const char* e = getenv("ND4HIP_LU_LA_MAX_BATCH"); return e ? atoi(e) : 12; }();
+  static const int nbo_batch = [] { const char* e = getenv("ND4HIP_LU_BATCH_OUTER"); return e ? atoi(e) : 128; }();
+  const bool batch_two_level = batch > la_max_batch && nbo_batch >= 32 && N <= 2048 && N >= 4 * nbo_batch;
+  const int NBO = (N > 2048 && nbo_env >= 32) ? nbo_env : (batch_two_level ? nbo_batch : N);
   void* u12buf = nullptr;
   if (NBO < N) ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * NBO * N, &u12buf));
   // panels taller than 2048 rows: the rows over P co-resident workgroups of 512 threads x R rows (lu_panel_mw), 16 columns wide
@@ -1128,7 +1134,12 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   const bool fused = !fuse_off && (N & 1) == 0;
   const long sStage = (long)NB * NB + (long)N * NB;
   double* stage = nullptr;
-  const bool la_on = !la_off && N >= 64 + NB && p_in_laswp;
+  // The look-ahead form (panel p in one workgroup, panel p - 1's column-block updates riding in the same launch) hides a latency
+  // chain behind otherwise idle CUs: right for one or a few matrices. A batch that fills the chip by itself is a throughput
+  // problem, for which the plain sequence panel -> interchanges + U12 -> rank-16 product on the MFMA kernel moves fewer bytes per
+  // launch (1024 x 512^2: 73.9 ms with the look-ahead form, 19.8 ms without; 8 matrices: 1.05 against 1.37 ms, 16: 1.64 against
+  // 1.48). ND4HIP_LU_LA_MAX_BATCH moves the switch.
+  const bool la_on = !la_off && N >= 64 + NB && p_in_laswp && batch <= la_max_batch;
   if (la_on) {
     void* stg = nullptr;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * sStage, &stg));
@@ -1206,7 +1217,16 @@ static int getrf_impl(nd4hip_handle* h, int64_t batch, int64_t N64, const double
   // phase 2: the look-ahead form on the whole matrix (N <= 2048) or on the trailing <= 2048 rows of a larger one
   if (la_on && N - j_start <= 2048 && N - j_start >= 64 + NB) ND4_TRY(la_range(j_start, N, N, &j_start));
   // phase 3: what is left (short panels after the look-ahead form; everything when it is switched off), one level
-  if (j_start < N) ND4_TRY(outer_block(j_start, N, false));
+  if (j_start < N) {
+    if (batch_two_level && !la_on) {
+      for (int J = j_start; J < N; J += NBO) {
+        const int bend = J + NBO < N ? J + NBO : N;
+        ND4_TRY(outer_block(J, bend, bend < N));
+      }
+    } else {
+      ND4_TRY(outer_block(j_start, N, false));
+    }
+  }
   if (mw_on && p_in_laswp) hipLaunchKernelGGL(lu_mw_poison, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, P, total, stuck, h->xstat);
   if (p_in_laswp) { ND4_HIP(hipGetLastError()); return 0; }
   if ((size_t)N * sizeof(int32_t) <= 60 * 1024)

@@ -676,6 +676,9 @@ struct QrhP {
   int drop_tag;                     // tests only (ND4HIP_TEST_DROP_PUBLISH): the last row workgroup of the panel with this tag skips its first publication
 };
 
+#include "qr_chain16.h"
+
+// (round 3's unblocked chains: kept behind -DND4HIP_QR_OLD_CHAINS for A/B builds)
 template <int K, int I>
 __device__ __forceinline__ void qrh_ge_row(double (&g)[16], double gk) {
   if constexpr (I > K) g[I] = fma(-nd4dpp::rl_d(g[I], K), gk, g[I]);
@@ -769,6 +772,13 @@ __device__ __forceinline__ void qrh_gj16(const double* __restrict__ s_Z, double*
   }
 }
 
+#ifdef ND4HIP_QR_OLD_CHAINS
+#define ND4_CHOL16 qrh_chol16
+#define ND4_GJ16 qrh_gj16
+#else
+#define ND4_CHOL16 qrc_chol16_inv      // the eliminations on the matrix core (qr_chain16.h)
+#define ND4_GJ16 qrc_gj16
+#endif
 constexpr int QRH_LDS = 8 * 256 + 256 + NB * (NB + 1) + 16;      // doubles: what the row phases and the side work need ...
 constexpr int QRH_SMEM = QRH_LDS + 11 * 256 + 32;                // ... and the whole per-workgroup buffer: phase C carves its 16 x 16 matrices behind QRH_LDS
 
@@ -1190,7 +1200,7 @@ __global__ __launch_bounds__(512) void qrh_chol(const QrhP P) {
   qrh_stamp(P, 1);
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);                                     // the chain wave shares its CU with riding side workgroups
-    bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
+    bool ok = ND4_CHOL16(s_G, s_R, s_Ri, HR_PIVOT_THR);
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < 16; k++) ok = ok && (s_db[k] > 0.0);
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   } else {
     if (t < 256) s_E[t] += (i == j) ? 1.0 : 0.0;
     __syncthreads();
-    if (wave == 0) (void)qrh_chol16(s_E, s_R2, s_R2i, 0.0);
+    if (wave == 0) (void)ND4_CHOL16(s_E, s_R2, s_R2i, 0.0);
   }
   __syncthreads();
   if (t < 256) {
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(512) void qrh_reconstruct(const QrhP P) {
   }
   __syncthreads();
   qrh_stamp(P, 3);
-  if (wave == 0) { __builtin_amdgcn_s_setprio(3); qrh_gj16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
+  if (wave == 0) { __builtin_amdgcn_s_setprio(3); ND4_GJ16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
   double bw[4];
 #pragma unroll
   for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
@@ -1640,7 +1650,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   // ---- phase B: R1 = chol(G), the fall-back decision ----
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
-    bool ok = qrh_chol16(s_G, s_R, s_Ri, HR_PIVOT_THR);
+    bool ok = ND4_CHOL16(s_G, s_R, s_Ri, HR_PIVOT_THR);
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int k = 0; k < 16; k++) ok = ok && (s_db[k] > 0.0);
@@ -1782,7 +1792,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
   } else {
     if (t < 256) s_E[t] += (i == j) ? 1.0 : 0.0;
     __syncthreads();
-    if (wave == 0) (void)qrh_chol16(s_E, s_R2, s_R2i, 0.0);
+    if (wave == 0) (void)ND4_CHOL16(s_E, s_R2, s_R2i, 0.0);
   }
   __syncthreads();
   if (g == 0) {                                                        // only workgroup 0 holds the top block: Z, R, K, S
@@ -1797,7 +1807,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     }
     __syncthreads();
     qrh_stamp(P, 5);
-    if (wave == 0) { __builtin_amdgcn_s_setprio(3); qrh_gj16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
+    if (wave == 0) { __builtin_amdgcn_s_setprio(3); ND4_GJ16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
   }
 #pragma unroll
   for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
@@ -2201,7 +2211,6 @@ __global__ __launch_bounds__(256) void qr_t_assemble(double* __restrict__ Tall, 
   Tall[so + t] = s_t[i][j];
 }
 
-#include "qr_chain16.h"
 #include "qr_batched_panel.h"
 
 template <int R, int NWV = 8>
@@ -2524,7 +2533,11 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   static const bool la_off = [] { const char* e = getenv("ND4HIP_QR_NO_LOOKAHEAD"); return e && *e && *e != '0'; }();
   static const bool wy_off = [] { const char* e = getenv("ND4HIP_QR_NO_WY"); return e && *e && *e != '0'; }();
   static const bool qt_off = [] { const char* e = getenv("ND4HIP_QR_NO_QT"); return e && *e && *e != '0'; }();
-  const bool lookahead = !la_off && M <= 2048 && M >= 64;
+  // (like LU: the look-ahead launches serve few matrices; a batch that fills the chip takes the plain sequence with the
+  //  matrix-core panels of qr_batched_panel.h: 1024 x 512^2 48.6 -> 43.7 ms; 8 matrices 1.97 against 2.53 ms, 32: 2.91 against 2.87.
+  //  ND4HIP_QR_LA_MAX_BATCH moves the switch.)
+  static const int la_max_batch = [] { const char* e = getenv("ND4HIP_QR_LA_MAX_BATCH"); return e ? atoi(e) : 24; }();
+  const bool lookahead = !la_off && M <= 2048 && M >= 64 && batch <= la_max_batch;
   const bool use_qt = lookahead && !wy_off && !qt_off && batch <= 4 && L >= 256;   // Q^T accumulated in the shadow of the panels
   const long sQT = use_qt ? (long)M * M : 0;
   static const bool hr_off = [] { const char* e = getenv("ND4HIP_QR_NO_HR"); return e && *e && *e != '0'; }();

@@ -50,28 +50,81 @@ __device__ __forceinline__ bool qrc_chol16(d4 g, double thr, double (&rrow)[4], 
   return __ballot(bad) == 0ull;
 }
 
+// ---- Cholesky with the inverse factor: the row operations of the elimination applied to the identity as well (one more MFMA per
+//      pivot, independent of the first) leave Y = (unit lower L)^-1; R^-1[r][c] = Y[c][r] / R[c][c] ----
+template <int K>
+__device__ __forceinline__ void qrc_chol_inv_step(d4& g, d4& y, double (&rrow)[4], double (&rsreg)[4], int fx, int fk) {
+  constexpr int RG = K / 4, SL = K % 4;
+  const double p = qrc_rl(g[RG], 16 * SL + K);
+  const double rs = nd4dpp::fast_rsqrt(p);
+  const bool slot = fk == SL;
+  const double u = (slot && fx >= K) ? g[RG] * rs : 0.0;
+  rrow[RG] = slot ? u : rrow[RG];
+  rsreg[RG] = slot ? rs : rsreg[RG];
+  if constexpr (K < 15) {
+    const double mneg = (fx > K) ? -(u * rs) : 0.0;                    // -G[fx][K] / p for the rows below the pivot (zero outside the k-slot: u is)
+    y = __builtin_amdgcn_mfma_f64_16x16x4f64(mneg, slot ? y[RG] : 0.0, y, 0, 0, 0);   // rows i > K of Y -= m_i * row K of Y
+    g = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, g, 0, 0, 0);
+  }
+}
+template <int... K>
+__device__ __forceinline__ void qrc_chol_inv_all(d4& g, d4& y, double (&rrow)[4], double (&rsreg)[4], int fx, int fk, std::integer_sequence<int, K...>) {
+  (qrc_chol_inv_step<K>(g, y, rrow, rsreg, fx, fk), ...);
+}
+// One wave; drop-in for qrh_chol16: s_G symmetric positive definite 16 x 16 (row major, all 256 entries). Out: s_R = chol(G)^T
+// (upper, G = R^T R) and s_Ri = R^-1 (upper), row major. Returns true when every pivot is positive and >= thr * its diagonal entry.
+__device__ __forceinline__ bool qrc_chol16_inv(const double* __restrict__ s_G, double* __restrict__ s_R, double* __restrict__ s_Ri, double thr) {
+  const int lane = threadIdx.x & 63, fx = lane & 15, fk = lane >> 4;
+  d4 g, y;
+  double rrow[4], rsreg[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { g[r] = s_G[(4 * r + fk) * 16 + fx]; y[r] = (fx == 4 * r + fk) ? 1.0 : 0.0; rrow[r] = 0.0; rsreg[r] = 0.0; }
+  const d4 g0 = g;
+  qrc_chol_inv_all(g, y, rrow, rsreg, fx, fk, std::make_integer_sequence<int, 16>{});
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const double d = rrow[r], o = g0[r];
+    bad = bad || (fx == 4 * r + fk && !(d > 0.0 && d * d >= thr * o && o < DBL_MAX));
+    s_R[(4 * r + fk) * 16 + fx] = d;
+    s_Ri[fx * 16 + 4 * r + fk] = (fx <= 4 * r + fk) ? y[r] * rsreg[r] : 0.0;   // R^-1[fx][c] = Y[c][fx] / R[c][c], c = 4 r + fk
+  }
+  return __ballot(bad) == 0ull;
+}
+
 // ---- Gauss-Jordan inversion of B = Z - S in place, S_k = -sign(pivot) chosen on the way (every pivot p - s has magnitude >= 1) ----
 // In-place step k on T (with uf = column k, r = row k, p = T[k][k], inv = 1 / (p - s), c = (p + 1) inv):
 //   T' = T - uf w1^T + e_k w2^T,   w1 = r inv (entry k: inv + 1),   w2 = r (c - 1) (entry k: c)
 // i.e. T'[i][j] = T[i][j] - T[i][k] T[k][j] inv, T'[i][k] = -T[i][k] inv, T'[k][j] = T[k][j] inv, T'[k][k] = inv. Row k of T is
 // rewritten exactly after the MFMA; the transpose is carried along (column k of T is row k of T^T: the A operand), its column k
-// fixed by the second rank-1 term.
+// fixed by the second rank-1 term, which rides in another k-slot of the same MFMA (w2 crosses 32 lanes by v_permlane32_swap).
+// value of lane ^ 32 (the same fx, k-slot fk ^ 2), valid in the lanes of k-slot SL2: v_permlane32_swap exchanges lanes [32, 64) of
+// its first operand with lanes [0, 32) of its second
+template <int SL2>
+__device__ __forceinline__ double qrc_from_other_half(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return SL2 >= 2 ? __hiloint2double(hi[0], lo[0]) : __hiloint2double(hi[1], lo[1]);
+}
 template <int K>
 __device__ __forceinline__ void qrc_gj_step(d4& t, d4& tt, double (&sreg)[4], int fx, int fk) {
-  constexpr int RG = K / 4, SL = K % 4;
+  constexpr int RG = K / 4, SL = K % 4, SL2 = SL ^ 2;
   const double p = qrc_rl(t[RG], 16 * SL + K);
   const double s = (p >= 0.0) ? -1.0 : 1.0;
   const double inv = nd4dpp::fast_rcp(p - s);
-  const double c = (p + 1.0) * inv;
+  const double cm1 = fma(p + 1.0, inv, -1.0);                          // c - 1
   const bool slot = fk == SL, col = fx == K;
+  const double ecol = col ? 1.0 : 0.0, e2 = (fk == SL2 && col) ? 1.0 : 0.0;   // (constants of the step)
   const double r = t[RG], uf = tt[RG];                                 // at the slot lanes: T[K][fx], T[fx][K]
-  const double v = col ? inv : r * inv;                                // the new row K
-  const double w1 = col ? inv + 1.0 : v;
-  const double w2 = col ? c : r * (c - 1.0);
-  t = __builtin_amdgcn_mfma_f64_16x16x4f64(slot ? -uf : 0.0, slot ? w1 : 0.0, t, 0, 0, 0);
-  t[RG] = slot ? v : t[RG];
-  tt = __builtin_amdgcn_mfma_f64_16x16x4f64(slot ? -w1 : 0.0, slot ? uf : 0.0, tt, 0, 0, 0);
-  tt = __builtin_amdgcn_mfma_f64_16x16x4f64(slot ? w2 : 0.0, (slot && col) ? 1.0 : 0.0, tt, 0, 0, 0);
+  const double vk = col ? inv : r * inv;                               // the new row K
+  const double w1n = fma(vk, -1.0, -ecol);                             // -w1
+  const double w2 = col ? cm1 + 1.0 : r * cm1;
+  const double w2s = qrc_from_other_half<SL2>(w2);                     // w2 in the lanes of k-slot SL2
+  // T -= uf w1^T: only the B operand is masked to its k-slot (the other slots of A meet zeros there)
+  t = __builtin_amdgcn_mfma_f64_16x16x4f64(uf, slot ? w1n : 0.0, t, 0, 0, 0);
+  t[RG] = slot ? vk : t[RG];
+  // T^T += (-w1) uf^T in k-slot SL and w2 e_K^T in k-slot SL2: one MFMA
+  tt = __builtin_amdgcn_mfma_f64_16x16x4f64(fk == SL2 ? w2s : w1n, slot ? uf : e2, tt, 0, 0, 0);
   sreg[RG] = slot ? s : sreg[RG];
 }
 template <int... K>

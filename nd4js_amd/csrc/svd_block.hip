@@ -802,7 +802,10 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
         hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)npairs, (unsigned)nchunks, (unsigned)batch), dim3(256), 0, h->stream,
                            W, N, sM, nblk, nblk2, step, st, Gpart, nchunks, sG, 0);
       if (cross_only && defer) {
-        hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(npairs + npairs * nchunks), (unsigned)batch), dim3(576), 0, h->stream,
+        // dynamic LDS on top of the kernel's ~70 KB: above 80 KB in all a rotation workgroup has its CU to itself (the riding U
+        // workgroups go elsewhere): its rounds are bound by the instruction issue of that one CU
+        static const int pad_kb = getenv("ND4HIP_JAC_EIGEN_PAD_KB") ? atoi(getenv("ND4HIP_JAC_EIGEN_PAD_KB")) : 0;
+        hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(npairs + npairs * nchunks), (unsigned)batch), dim3(576), (size_t)pad_kb * 1024, h->stream,
                            Gpart, nchunks, sG, nblk, nblk2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, npairs,
                            Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1], 0);
       } else if (cross_only) {
