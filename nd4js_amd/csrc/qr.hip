@@ -1762,6 +1762,19 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+#ifndef ND4HIP_QR_OLD_CHAINS
+  // R2 and R2^-1 on wave 0 (the products of the series on the matrix core, qr_chain16.h), then — workgroup 0 — the top block of Q,
+  // R = R2 R1 and the elimination behind S and K, while the other waves form Q = Q1 R2^-1
+  if (wave == 0) qrc_series16(s_E, series, s_R2, s_R2i, s_F);
+  __syncthreads();
+  if (g == 0 && wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    qrc_zr16(s_Qt, s_R2i, s_R2, s_R, s_Z, s_Rm);
+    qrh_stamp(P, 5);
+    qrc_gj16(s_Z, s_K, s_S);
+    __builtin_amdgcn_s_setprio(0);
+  }
+#else
   if (series) {
     if (t < 256) {
       double pp = 0.0;
@@ -1809,6 +1822,7 @@ __global__ __launch_bounds__(512) void qrh_bc(const QrhP P) {
     qrh_stamp(P, 5);
     if (wave == 0) { __builtin_amdgcn_s_setprio(3); ND4_GJ16(s_Z, s_K, s_S); __builtin_amdgcn_s_setprio(0); }
   }
+#endif
 #pragma unroll
   for (int kk = 0; kk < 4; kk++) bw[kk] = s_R2i[(4 * fk + kk) * 16 + fx];
   d4 y[4];
@@ -2892,6 +2906,16 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
     static const bool stamps_on = [] { const char* e = getenv("ND4HIP_QRB_STAMPS"); return e && *e && *e != '0'; }();
     long long* stamps = nullptr;
     if (stamps_on) { static long long* dbuf = nullptr; if (!dbuf) ND4_HIP(hipMalloc(&dbuf, 512)); stamps = dbuf; }
+    static const bool copy_only = [] { const char* e = getenv("ND4HIP_QRB_COPY_ONLY"); return e && *e && *e != '0'; }();
+    static const int copy_mode = [] { const char* e = getenv("ND4HIP_QRB_COPY_ONLY"); return e ? atoi(e) : 0; }();
+    if (copy_only) {                                                   // debug: the kernel's data movement alone (see qrb_copy_only)
+      if (M <= 256)       hipLaunchKernelGGL((qrb_copy_only<4, 1>), dim3(batch), dim3(64), 0, h->stream, A, M, (long)NB, sW, V, (long)NB, sW, 0, copy_mode);
+      else if (M <= 512)  hipLaunchKernelGGL((qrb_copy_only<4, 2>), dim3(batch), dim3(128), 0, h->stream, A, M, (long)NB, sW, V, (long)NB, sW, 0, copy_mode);
+      else if (M <= 1024) hipLaunchKernelGGL((qrb_copy_only<4, 4>), dim3(batch), dim3(256), 0, h->stream, A, M, (long)NB, sW, V, (long)NB, sW, 0, copy_mode);
+      else                hipLaunchKernelGGL((qrb_copy_only<4, 8>), dim3(batch), dim3(512), 0, h->stream, A, M, (long)NB, sW, V, (long)NB, sW, 0, copy_mode);
+      ND4_HIP(hipGetLastError());
+      return 0;
+    }
     launch_panel_mfma<false>(h, batch, A, M, M, NB, sW, V, NB, sW, T, NB * NB, taus, NB, 0, stamps);
     ND4_HIP(hipGetLastError());
     if (stamps) {

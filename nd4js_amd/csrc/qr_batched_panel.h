@@ -124,6 +124,57 @@ __device__ __attribute__((noinline)) void qrb_fallback(int mat, double* Wm, int 
 constexpr int QRB_SMALL = 7 * 256 + 64;                                // doubles of LDS besides the per-wave staging and partial slots
 template <int NWV> constexpr int qrb_lds_doubles() { return NWV * (1024 + 256) + QRB_SMALL; }
 
+// The data movement of qrb_panel alone (debug, ND4HIP_QRB_COPY_ONLY=1: the entry point then copies A to V and computes nothing): the
+// ceiling the panel kernel's own access pattern sets — thread-per-row 16-byte loads and stores, one workgroup of 64 NWV threads per
+// panel, every workgroup streaming its own contiguous panel. Measured (round 4, bench protocol of ops.qr_panel): 256 x 2048 rows
+// 40.0 us = 3.35 TB/s = 42 % of the HBM peak, 2048 x 512 rows 71.7 us = 47 % (mode 3 = each row slot stored as soon as it has
+// arrived: 38.9 / 70.2 us); the same bytes through a plain device copy (tools/copy_bw.py): 24.6 us = 5.5 TB/s. A variant with
+// full-line accesses (a wave instruction = 8 whole 128-byte rows) was SLOWER: 50.8 / 95.5 us.
+template <int R, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void qrb_copy_only(const double* __restrict__ Wm, int M, long ld, long strideW,
+                                                             double* __restrict__ Vall, long ldv, long strideV, int j0, int mode) {
+  constexpr int TT = 64 * NWV;
+  const int mat = blockIdx.x, t = threadIdx.x;
+  if (mode == 3) {                                                     // every row slot stored as soon as it has arrived
+    const double* A3 = Wm + mat * strideW;
+    double* V3 = Vall + mat * strideV;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const int r = j0 + t + TT * i;
+      if (r < M) {
+        double2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const double2*>(A3 + (long)r * ld + j0 + 2 * c);
+#pragma unroll
+        for (int c = 0; c < 8; c++) *reinterpret_cast<double2*>(V3 + (long)r * ldv + j0 + 2 * c) = v[c];
+      }
+      asm volatile("" ::: "memory");
+    }
+    return;
+  }
+  const double* A = Wm + mat * strideW;
+  double* V = Vall + mat * strideV;
+  double a[R][NB];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + TT * i;
+    if (r < M) {
+      const double* src = A + (long)r * ld + j0;
+#pragma unroll
+      for (int c = 0; c < NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int r = j0 + t + TT * i;
+    if (r < M) {
+      double* v = V + (long)r * ldv + j0;
+#pragma unroll
+      for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(v + c) = double2{a[i][c], a[i][c + 1]};
+    }
+  }
+}
+
 template <int R, int NWV, bool ZERO>
 __global__ __launch_bounds__(64 * NWV, 2) void qrb_panel(double* __restrict__ Wm, int M, long ld, long strideW,
                                                       double* __restrict__ Vall, long ldv, long strideV,

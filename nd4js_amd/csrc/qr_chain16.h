@@ -146,3 +146,81 @@ __device__ __forceinline__ void qrc_gj16(const double* __restrict__ s_Z, double*
     if (fx == 0) s_S[4 * r + fk] = sreg[r];
   }
 }
+
+// ---- the small products of CholeskyQR2's second pass on one wave (round 3: 256 threads, four barriers, ~2.7 us) ----
+// images of a row-major 16 x 16 matrix in LDS: the accumulator image (B operand "rows 4r..4r+3") and the image of its transpose
+// (A operand "columns 4r..4r+3")
+__device__ __forceinline__ d4 qrc_img(const double* __restrict__ s, int fx, int fk) {
+  d4 x;
+#pragma unroll
+  for (int r = 0; r < 4; r++) x[r] = s[(4 * r + fk) * 16 + fx];
+  return x;
+}
+__device__ __forceinline__ d4 qrc_img_t(const double* __restrict__ s, int fx, int fk) {
+  d4 x;
+#pragma unroll
+  for (int r = 0; r < 4; r++) x[r] = s[fx * 16 + 4 * r + fk];
+  return x;
+}
+__device__ __forceinline__ void qrc_put(double* __restrict__ s, const d4& x, int fx, int fk) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) s[(4 * r + fk) * 16 + fx] = x[r];
+}
+// A B for A given as the image of A^T and B as its accumulator image
+__device__ __forceinline__ d4 qrc_mul(const d4& at, const d4& b) {
+  d4 c = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; r++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(at[r], b[r], c, 0, 0, 0);
+  return c;
+}
+#define QRC_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// One wave. s_E = Q1^T Q1 - I (row major). Out (row major): s_R2 = chol(I + E)^T and s_R2i = R2^-1.
+// series: R2 = I + F, F = triu(E - F0^T F0) with the diagonal halved, F0 = triu(E) likewise (two fixed-point steps: error O(|E|^3));
+// R2^-1 = (I - F)(I + F^2) (error O(|F|^4)). Otherwise (max|E| > HR_SERIES_MAX) the elimination chain on I + E. s_tmp: 256 doubles.
+__device__ __forceinline__ void qrc_series16(double* __restrict__ s_E, bool series, double* __restrict__ s_R2, double* __restrict__ s_R2i,
+                                             double* __restrict__ s_tmp) {
+  const int lane = threadIdx.x & 63, fx = lane & 15, fk = lane >> 4;
+  if (!series) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (fx == 4 * r + fk) s_E[fx * 17] += 1.0;
+    QRC_LDS_SYNC();
+    (void)qrc_chol16_inv(s_E, s_R2, s_R2i, 0.0);
+    QRC_LDS_SYNC();
+    return;
+  }
+  const d4 ev = qrc_img(s_E, fx, fk);
+  d4 f0, f1, eye;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = 4 * r + fk;
+    eye[r] = (i == fx) ? 1.0 : 0.0;
+    f0[r] = (i < fx) ? ev[r] : ((i == fx) ? 0.5 * ev[r] : 0.0);
+  }
+  d4 pp = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; r++) pp = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[r], f0[r], pp, 0, 0, 0);      // F0^T F0: a Gram product of the image with itself
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = 4 * r + fk;
+    const double x = ev[r] - pp[r];
+    f1[r] = (i < fx) ? x : ((i == fx) ? 0.5 * x : 0.0);
+  }
+  qrc_put(s_tmp, f1, fx, fk);
+  qrc_put(s_R2, f1 + eye, fx, fk);
+  QRC_LDS_SYNC();
+  const d4 f1t = qrc_img_t(s_tmp, fx, fk);
+  const d4 f2 = qrc_mul(f1t, f1);                                      // F F
+  const d4 r2i = qrc_mul(eye - f1t, f2 + eye);                         // (I - F)(I + F^2)   (the identity is symmetric: one image)
+  qrc_put(s_R2i, r2i, fx, fk);
+  QRC_LDS_SYNC();
+}
+// One wave. s_Z = Qt R2^-1 (the top block of Q) and s_Rm = R2 R1, row major in and out.
+__device__ __forceinline__ void qrc_zr16(const double* __restrict__ s_Qt, const double* __restrict__ s_R2i, const double* __restrict__ s_R2,
+                                         const double* __restrict__ s_R1, double* __restrict__ s_Z, double* __restrict__ s_Rm) {
+  const int lane = threadIdx.x & 63, fx = lane & 15, fk = lane >> 4;
+  const d4 z = qrc_mul(qrc_img_t(s_Qt, fx, fk), qrc_img(s_R2i, fx, fk));
+  const d4 rm = qrc_mul(qrc_img_t(s_R2, fx, fk), qrc_img(s_R1, fx, fk));
+  qrc_put(s_Z, z, fx, fk);
+  qrc_put(s_Rm, rm, fx, fk);
+  QRC_LDS_SYNC();
+}
