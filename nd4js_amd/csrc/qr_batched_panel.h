@@ -21,23 +21,46 @@
 // ZERO: rows below the top block of the panel's columns in W are zeroed (the in-matrix panels of the batched QR driver); the
 // panel entry point leaves them alone, so a panel moves its algorithmic 16 m b bytes and nothing else.
 
-// element (row l of the wave's 64, column c) of a staged slot: rows of 128 bytes, 16-byte piece p of row l at piece p ^ (l & 7)
-__device__ __forceinline__ int qrb_off(int l, int c) { return l * 16 + ((((c >> 1) ^ (l & 7)) << 1) | (c & 1)); }
+// A staged slot = 64 rows of 128 bytes in a wave's own 8 KB of LDS; the 16-byte piece p of row l sits at piece p ^ qrb_sw(l).
+// sw(l) = (l1, l2, l0 ^ l3) (bits of l) makes every access pattern of the kernel conflict free: row-wise 16-byte writes and reads
+// (lane = row: 8 consecutive rows give 8 different pieces; the 16 lanes of a ds_read_b128 group — {0-3, 12-15, 20-27}, ... — give
+// 16 different (row parity, piece) pairs), line-wise 16-byte writes and reads (lane = (row 8k + l / 8, piece l % 8): the global
+// side of the kernel) and the 8-byte tile reads of the Gram product (two rows of opposite parity per group).
+__device__ __forceinline__ int qrb_sw(int l) { return ((l >> 1) & 3) | (((l ^ (l >> 3)) & 1) << 2); }
+__device__ __forceinline__ int qrb_off(int l, int c) { return l * 16 + ((((c >> 1) ^ qrb_sw(l)) << 1) | (c & 1)); }
 
 // Gram matrix of the wave's R x 64 rows -> g (accumulator image: g[r] of lane (fx, fk) = G[fk + 4 r][fx]); with s_top != nullptr
 // the first 16-row tile of slot 0 is left out of g and its own Gram matrix goes to s_top (row major)
-template <int R>
-__device__ __forceinline__ void qrb_gram(double* __restrict__ s_st, const double (&a)[R][NB], double* __restrict__ s_top, d4& g) {
+// LINES: the slot arrives from global memory as whole lines (ln[i][k] of lane l = piece l % 8 of row 8 k + l / 8 of slot i) and is
+// staged from there; the rows' registers a are then READ from the staged slot (thread-per-row), after the tile reads of the Gram product.
+template <int R, bool LINES = false>
+__device__ __forceinline__ void qrb_gram(double* __restrict__ s_st, double (&a)[R][NB], double* __restrict__ s_top, d4& g,
+                                         const double2 (*ln)[8] = nullptr) {
   int lane = threadIdx.x & 63;
   asm volatile("" : "+v"(lane));                                       // (see qrb_park)
   const int fx = lane & 15, fk = lane >> 4;
   d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
   for (int i = 0; i < R; i++) {
+    if constexpr (LINES) {
 #pragma unroll
-    for (int p = 0; p < 8; p++)
-      *reinterpret_cast<double2*>(s_st + lane * 16 + ((p ^ (lane & 7)) << 1)) = double2{a[i][2 * p], a[i][2 * p + 1]};
+      for (int k = 0; k < 8; k++) {
+        const int row = 8 * k + (lane >> 3);
+        *reinterpret_cast<double2*>(s_st + row * 16 + (((lane & 7) ^ qrb_sw(row)) << 1)) = ln[i][k];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; p++)
+        *reinterpret_cast<double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1)) = double2{a[i][2 * p], a[i][2 * p + 1]};
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (the DS operations of one wave execute in order)
+    if constexpr (LINES) {
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        const double2 v = *reinterpret_cast<const double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1));
+        a[i][2 * p] = v.x; a[i][2 * p + 1] = v.y;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       double c[4];
@@ -98,7 +121,7 @@ __device__ __forceinline__ void qrb_park(const double (&a)[R][NB], double* __res
   for (int u = 0; u < NP; u++) {
 #pragma unroll
     for (int p = 0; p < 8; p++)
-      *reinterpret_cast<double2*>(s_st + u * 1024 + lane * 16 + ((p ^ (lane & 7)) << 1)) = double2{a[R - 1 - u][2 * p], a[R - 1 - u][2 * p + 1]};
+      *reinterpret_cast<double2*>(s_st + u * 1024 + lane * 16 + ((p ^ qrb_sw(lane)) << 1)) = double2{a[R - 1 - u][2 * p], a[R - 1 - u][2 * p + 1]};
   }
 }
 template <int R, int NP>
@@ -108,7 +131,7 @@ __device__ __forceinline__ void qrb_unpark(double (&a)[R][NB], const double* __r
   for (int u = 0; u < NP; u++) {
 #pragma unroll
     for (int p = 0; p < 8; p++) {
-      const double2 v = *reinterpret_cast<const double2*>(s_st + u * 1024 + lane * 16 + ((p ^ (lane & 7)) << 1));
+      const double2 v = *reinterpret_cast<const double2*>(s_st + u * 1024 + lane * 16 + ((p ^ qrb_sw(lane)) << 1));
       a[R - 1 - u][2 * p] = v.x; a[R - 1 - u][2 * p + 1] = v.y;
     }
   }
@@ -135,6 +158,53 @@ __global__ __launch_bounds__(64 * NWV, 2) void qrb_copy_only(const double* __res
                                                              double* __restrict__ Vall, long ldv, long strideV, int j0, int mode) {
   constexpr int TT = 64 * NWV;
   const int mat = blockIdx.x, t = threadIdx.x;
+  if (mode == 2) {                                                     // full-line accesses: a wave instruction = 8 whole 128-byte rows
+    const double* A3 = Wm + mat * strideW;
+    double* V3 = Vall + mat * strideV;
+    const int lane = t & 63, wave = t >> 6;
+    double2 v[R][8];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        int r = j0 + wave * 64 + TT * i + 8 * k + (lane >> 3);
+        r = r < M ? r : M - 1;                                           // (unconditional loads: all in flight)
+        v[i][k] = *reinterpret_cast<const double2*>(A3 + (long)r * ld + j0 + 2 * (lane & 7));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int r = j0 + wave * 64 + TT * i + 8 * k + (lane >> 3);
+        if (r < M) *reinterpret_cast<double2*>(V3 + (long)r * ldv + j0 + 2 * (lane & 7)) = v[i][k];
+      }
+    }
+    return;
+  }
+  if (mode == 4) {                                                     // non-temporal loads and stores
+    const double* A3 = Wm + mat * strideW;
+    double* V3 = Vall + mat * strideV;
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    dd2 v[R][8];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const int r = j0 + t + TT * i;
+      if (r < M) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[i][c] = __builtin_nontemporal_load(reinterpret_cast<const dd2*>(A3 + (long)r * ld + j0 + 2 * c));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const int r = j0 + t + TT * i;
+      if (r < M) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) __builtin_nontemporal_store(v[i][c], reinterpret_cast<dd2*>(V3 + (long)r * ldv + j0 + 2 * c));
+      }
+    }
+    return;
+  }
   if (mode == 3) {                                                     // every row slot stored as soon as it has arrived
     const double* A3 = Wm + mat * strideW;
     double* V3 = Vall + mat * strideV;
@@ -197,23 +267,25 @@ __global__ __launch_bounds__(64 * NWV, 2) void qrb_panel(double* __restrict__ Wm
   auto stamp = [&](int k) { if (stamps != nullptr && mat == 0 && t == 0) { stamps[2 * k] = wall_clock64(); stamps[2 * k + 1] = clock64(); } };   // 100 MHz wall clock, shader clock
   stamp(0);
 
+  // The panel comes in as whole 128-byte lines (a wave instruction = 8 rows: lane l takes piece l % 8 of row 8 k + l / 8 of its 64-row
+  // slot): the thread-per-row form of the same loads reached 3.4 TB/s on its own, this one 4.3 (qrb_copy_only, modes 1 / 2). The
+  // lines are staged in the wave's LDS slot, from which both the tiles of the Gram product and the rows' registers are read.
   double a[R][NB];
-#pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + t + TT * i;
-    if (r < M) {
-      const double* src = A + (long)r * ld + j0;
-#pragma unroll
-      for (int c = 0; c < NB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(src + c); a[i][c] = v.x; a[i][c + 1] = v.y; }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NB; c++) a[i][c] = 0.0;
-    }
-  }
-  // ---- G = C^T C (the top 16 rows apart: a column that is zero below them must take the fall-back) ----
   {
+    double2 ln[R][8];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int r = j0 + 64 * wave + TT * i + 8 * k + (lane >> 3);
+        const int rc = r < M ? r : M - 1;                              // (unconditional loads: all of them in flight at once)
+        const double2 v = *reinterpret_cast<const double2*>(A + (long)rc * ld + j0 + 2 * (lane & 7));
+        ln[i][k] = r < M ? v : double2{0.0, 0.0};
+      }
+    }
+    // ---- G = C^T C (the top 16 rows apart: a column that is zero below them must take the fall-back) ----
     d4 g;
-    qrb_gram<R>(s_st + wave * 1024, a, wave == 0 ? s_X + 256 : nullptr, g);
+    qrb_gram<R, true>(s_st + wave * 1024, a, wave == 0 ? s_X + 256 : nullptr, g, ln);
 #pragma unroll
     for (int r = 0; r < 4; r++) s_part[wave * 256 + (fk + 4 * r) * 16 + fx] = g[r];
   }
@@ -331,32 +403,48 @@ __global__ __launch_bounds__(64 * NWV, 2) void qrb_panel(double* __restrict__ Wm
 #pragma unroll
       for (int c = 0; c < NB; c++) s_Z[t * 16 + c] = a[0][c];
     }
-    qrb_park<R, NP>(a, s_st, lane);
+    qrb_park<R, 1>(a, s_st, lane);                                     // (its own slot only: the other waves are staging their stores in theirs)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     qrc_gj16(s_Z, s_K, s_S);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    qrb_unpark<R, NP>(a, s_st, lane);
+    qrb_unpark<R, 1>(a, s_st, lane);
     if (t < NB) sg = s_S[t];
   }
   stamp(11);
+  // V goes out as whole lines too: each slot from the rows' registers through the wave's LDS slot (row-wise writes, line-wise
+  // reads), one slot behind the next one's writes. The top block's rows carry V = Q - S; R = S R2 R1 is written by its 16 lanes.
+  if (t < NB) {
 #pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int r = j0 + t + TT * i;
-    if (r < M) {
-      double* v = V + (long)r * ldv + j0;
-      double* w = A + (long)r * ld + j0;
-      if (i == 0 && t < NB) {                                          // the top block: V = Q - S, R = S R2 R1 in place
+    for (int c = 0; c < NB; c++) a[0][c] -= (c == t) ? sg : 0.0;
+    double* w = A + (long)(j0 + t) * ld + j0;
 #pragma unroll
-        for (int c = 0; c < NB; c += 2) {
-          *reinterpret_cast<double2*>(v + c) = double2{a[0][c] - ((c == t) ? sg : 0.0), a[0][c + 1] - ((c + 1 == t) ? sg : 0.0)};
-          *reinterpret_cast<double2*>(w + c) = double2{(t <= c) ? sg * s_Rm[t * 16 + c] : 0.0, (t <= c + 1) ? sg * s_Rm[t * 16 + c + 1] : 0.0};
-        }
-      } else {
+    for (int c = 0; c < NB; c += 2)
+      *reinterpret_cast<double2*>(w + c) = double2{(t <= c) ? sg * s_Rm[t * 16 + c] : 0.0, (t <= c + 1) ? sg * s_Rm[t * 16 + c + 1] : 0.0};
+  }
+  {
+    double* s_w = s_st + wave * 1024;
+    int ln_ = lane;
+    asm volatile("" : "+v"(ln_));                                      // (see qrb_park)
 #pragma unroll
-        for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(v + c) = double2{a[i][c], a[i][c + 1]};
-        if constexpr (ZERO) {
+    for (int i = 0; i < R; i++) {
 #pragma unroll
-          for (int c = 0; c < NB; c += 2) *reinterpret_cast<double2*>(w + c) = double2{0.0, 0.0};
+      for (int p = 0; p < 8; p++)
+        *reinterpret_cast<double2*>(s_w + ln_ * 16 + ((p ^ qrb_sw(ln_)) << 1)) = double2{a[i][2 * p], a[i][2 * p + 1]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double2 out[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int row = 8 * k + (ln_ >> 3);
+        out[k] = *reinterpret_cast<const double2*>(s_w + row * 16 + (((ln_ & 7) ^ qrb_sw(row)) << 1));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int r = j0 + 64 * wave + TT * i + 8 * k + (ln_ >> 3);
+        if (r < M) {
+          *reinterpret_cast<double2*>(V + (long)r * ldv + j0 + 2 * (ln_ & 7)) = out[k];
+          if constexpr (ZERO) {
+            if (r >= j0 + NB) *reinterpret_cast<double2*>(A + (long)r * ld + j0 + 2 * (ln_ & 7)) = double2{0.0, 0.0};
+          }
         }
       }
     }
