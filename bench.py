@@ -254,6 +254,20 @@ def main():
                     if k in pj:
                         out["roofline"][k] = pj[k]
                 break
+        # counter figures beside the time-derived fractions of the side ops (same passes, other kernels)
+        out["pmc"] = {}
+        for rnd in reversed(pmc):
+            for name in ("qr_panel_batched_pmc.json", "qr_lu_2048_pmc.json", "svd_small_pmc.json", "svd2048_pmc.json"):
+                f = os.path.join(ROOT, "profiles", rnd, name)
+                if name not in out["pmc"] and os.path.exists(f):
+                    try:
+                        with open(f) as fh:
+                            pj = json.load(fh)
+                        ks = pj.get("kernels", [pj])
+                        out["pmc"][name] = {"source": "profiles/%s/%s" % (rnd, name),
+                                            "traffic_bytes_per_launch": {k["kernel"]: k.get("traffic_bytes_per_launch") for k in ks if "kernel" in k}}
+                    except Exception as ex:  # pragma: no cover
+                        out["pmc"][name] = {"error": repr(ex)}
         # parity gates printed with the number and enforced
         parity = {"gate": 1e-10}
         with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:

@@ -97,7 +97,9 @@ int nd4hip_dgemm_ex_dev(nd4hip_handle* h, int transA, int transB, int64_t M, int
 /* ---- lu_decomp: replaces src/la/lu.js:24-81 ---------------------------------------------------
  * A [batch,N,N] -> LU [batch,N,N] (unit-L below the diagonal, U on/above) and the PERMUTATION
  * VECTOR P [batch,N] int32 with A[P[i],:] = (L*U)[i,:] (not LAPACK ipiv); pivot = first maximum of
- * |x| down the column (lu.js:48-52). */
+ * |x| down the column (lu.js:48-52). N > 2048 uses panels whose rows are spread over co-resident workgroups with one in-kernel
+ * exchange per column: should such an exchange time out, every entry of P is -1 (never a half-valid permutation) and the next
+ * synchronising entry point returns ND4HIP_ERR_XCHG; the host-pointer form returns it itself. */
 int nd4hip_dgetrf_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 int nd4hip_dgetrf_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* LU, int32_t* P);
 
@@ -217,9 +219,13 @@ int nd4hip_dgesvdj_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64
  * eliminates the same entries column by column with Givens rotations) ---------------------------------------------
  * A [batch,M,16] (1 <= M <= 2048) is overwritten with R in its top 16 x 16 (entries below the diagonal are left as the kernel
  * leaves them); V [batch,M,16] receives the panel's reflector block, T [batch,16,16] its factor: Q_panel = I - V T V^T is
- * orthogonal and Q_panel^T A = [R; 0]. Batches of more than 8 panels (and panels of fewer than 64 rows) take the thread-per-row
- * Householder kernel: V explicit unit lower trapezoidal, T upper triangular (compact WY). Up to 8 panels take the row-split form
- * (CholeskyQR2 + a compact orthogonal completion, three launches): V = Q - [S; 0] with a full top block, T a full 16 x 16 matrix.
+ * orthogonal and Q_panel^T A = [R; 0]. Panels of fewer than 64 rows take the thread-per-row Householder kernel: V explicit unit
+ * lower trapezoidal, T upper triangular (compact WY). Everything else is CholeskyQR2 + a compact orthogonal completion:
+ * V = Q - [S; 0] with a full top block, T a full 16 x 16 matrix — up to 8 panels as the row-split launch (the rows of a panel over
+ * co-resident workgroups), more than 8 as ONE workgroup per panel on the matrix cores (round 4, qr_batched_panel.h), which reads
+ * every element of A once and writes V once and nothing else: the rows of A below the top 16 are left untouched. A panel the Gram
+ * route must not take (nearly dependent columns, a column that is zero below the top block, non-finite data) is factorised by
+ * the thread-per-row kernel in the same launch (compact WY form, rows below R zeroed).
  * Device pointers. Exposed for the panel roofline of bench.py (16 M b bytes per panel). */
 int nd4hip_dgeqr2_panel_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t b, double* A, double* V, double* T);
 

@@ -47,7 +47,7 @@ def one(kernel, fcsv, wcsv, bcsv):
 def main():
     out, kernels, fcsv, wcsv = sys.argv[1:5]
     bcsv = sys.argv[5] if len(sys.argv) > 5 else None
-    ks = kernels.split(",")
+    ks = kernels.split(";") if ";" in kernels else kernels.split(",")      # (";" when a kernel name contains ", ")
     res = [one(k, fcsv, wcsv, bcsv) for k in ks]
     res = res[0] if len(res) == 1 else {"kernels": res}
     json.dump(res, open(out, "w"), indent=1)
