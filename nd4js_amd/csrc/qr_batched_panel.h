@@ -40,47 +40,62 @@ __device__ __forceinline__ void qrb_gram(double* __restrict__ s_st, double (&a)[
   asm volatile("" : "+v"(lane));                                       // (see qrb_park)
   const int fx = lane & 15, fk = lane >> 4;
   d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  // The DS operations of one wave execute in order, so slot i + 1 is written right behind the READS of slot i and lands while the
+  // 16 MFMAs of slot i run: the matrix pipe no longer idles through a write -> wait -> read round trip per slot.
+  auto stage = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    if constexpr (I < R) {
+      if constexpr (LINES) {
 #pragma unroll
-  for (int i = 0; i < R; i++) {
-    if constexpr (LINES) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int row = 8 * k + (lane >> 3);
-        *reinterpret_cast<double2*>(s_st + row * 16 + (((lane & 7) ^ qrb_sw(row)) << 1)) = ln[i][k];
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < 8; p++)
-        *reinterpret_cast<double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1)) = double2{a[i][2 * p], a[i][2 * p + 1]};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (the DS operations of one wave execute in order)
-    if constexpr (LINES) {
-#pragma unroll
-      for (int p = 0; p < 8; p++) {
-        const double2 v = *reinterpret_cast<const double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1));
-        a[i][2 * p] = v.x; a[i][2 * p + 1] = v.y;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      double c[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) c[r] = s_st[qrb_off(16 * q + 4 * r + fk, fx)];
-      if (q == 0 && i == 0 && s_top != nullptr) {                      // (uniform) the panel's top block: a Gram matrix of its own
-        d4 gt = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) gt = __builtin_amdgcn_mfma_f64_16x16x4f64(c[r], c[r], gt, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) s_top[(fk + 4 * r) * 16 + fx] = gt[r];
+        for (int k = 0; k < 8; k++) {
+          const int row = 8 * k + (lane >> 3);
+          *reinterpret_cast<double2*>(s_st + row * 16 + (((lane & 7) ^ qrb_sw(row)) << 1)) = ln[I][k];
+        }
       } else {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[0], c[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[1], c[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[2], c[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[3], c[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+          *reinterpret_cast<double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1)) = double2{a[I][2 * p], a[I][2 * p + 1]};
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  };
+  auto slot = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    if constexpr (I < R) {
+      if constexpr (LINES) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+          const double2 v = *reinterpret_cast<const double2*>(s_st + lane * 16 + ((p ^ qrb_sw(lane)) << 1));
+          a[I][2 * p] = v.x; a[I][2 * p + 1] = v.y;
+        }
+      }
+      double c[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) c[u] = s_st[qrb_off(16 * (u >> 2) + 4 * (u & 3) + fk, fx)];
+      asm volatile("" ::: "memory");                                   // (the next slot's writes stay behind these reads)
+      stage(std::integral_constant<int, I + 1>{});
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (q == 0 && I == 0 && s_top != nullptr) {                    // (uniform) the panel's top block: a Gram matrix of its own
+          d4 gt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < 4; r++) gt = __builtin_amdgcn_mfma_f64_16x16x4f64(c[r], c[r], gt, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_top[(fk + 4 * r) * 16 + fx] = gt[r];
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[4 * q], c[4 * q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[4 * q + 1], c[4 * q + 1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[4 * q + 2], c[4 * q + 2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c[4 * q + 3], c[4 * q + 3], acc1, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stage(std::integral_constant<int, 0>{});
+  slot(std::integral_constant<int, 0>{});
+  slot(std::integral_constant<int, 1>{});
+  slot(std::integral_constant<int, 2>{});
+  slot(std::integral_constant<int, 3>{});
 #pragma unroll
   for (int r = 0; r < 4; r++) g[r] = acc0[r] + acc1[r];
 }
