@@ -2860,15 +2860,11 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   return nd4_givens_signs(h, batch, M, L, N, tall && !full, Q, Lq, sQ, R, N, (long)Lr * N, ws.taus, ws.sTau, ws.flips);
 }
 
-// Sign convention of the reference's Givens-built factors, applied to a Householder-built pair (Q [M, >= L] with leading
-// dimension ldq, R [L, ncols] with leading dimension ldr; column j of Q and row j of R are flipped together):
-//   lu_rule = false (qr_decomp_full, the square / wide branches): R_jj >= 0 wherever a reflector was needed (tau_j != 0),
-//             and det Q = +1 (plane rotations) decides the last one when Q is square (M == L);
-//   lu_rule = true  (the c >= 0 branches for tall input, qr.js:97-139 / bidiag.js:49-61): every leading principal minor of
-//             Q's top L x L block is positive = positive pivots in its LU factorisation WITHOUT pivoting.
-// flips: L ints per matrix of scratch.
 // One panel factorisation on its own (the building block north_star's "HBM fraction on the QR panel" is quoted on):
-// A [batch, M, 16] -> R in the top 16 x 16 of A (in place), explicit unit-lower reflectors V [batch, M, 16], T [batch, 16, 16].
+// A [batch, M, 16] -> R in the top 16 x 16 of A (in place), the reflector block V [batch, M, 16] and its factor T [batch, 16, 16] with
+// Q_panel = I - V T V^T. Panels of < 64 rows: the thread-per-row Householder kernel (V unit lower trapezoidal, T upper triangular);
+// otherwise CholeskyQR2 + the compact orthogonal completion (V = Q - [S; 0], T = K full): up to 8 panels as the row-split launch
+// (qrh_bc), more as one workgroup per panel on the matrix cores (qr_batched_panel.h).
 int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, double* T) {
   Nd4WsScope scope(h);
   void* p = nullptr;
@@ -2935,6 +2931,13 @@ int nd4_geqr2_panel(nd4hip_handle* h, int batch, int M, double* A, double* V, do
   return 0;
 }
 
+// Sign convention of the reference's Givens-built factors, applied to a Householder-built pair (Q [M, >= L] with leading
+// dimension ldq, R [L, ncols] with leading dimension ldr; column j of Q and row j of R are flipped together):
+//   lu_rule = false (qr_decomp_full, the square / wide branches): R_jj >= 0 wherever a reflector was needed (tau_j != 0),
+//             and det Q = +1 (plane rotations) decides the last one when Q is square (M == L);
+//   lu_rule = true  (the c >= 0 branches for tall input, qr.js:97-139 / bidiag.js:49-61): every leading principal minor of
+//             Q's top L x L block is positive = positive pivots in its LU factorisation WITHOUT pivoting.
+// flips: L ints per matrix of scratch.
 int nd4_givens_signs(nd4hip_handle* h, int batch, int M, int L, int ncols, bool lu_rule, double* Q, long ldq, long sQ,
                      double* R, long ldr, long sR, const double* taus, long sTau, int* flips) {
   if (lu_rule) {

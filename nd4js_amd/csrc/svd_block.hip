@@ -721,7 +721,8 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
   // Measured: 4096^2 317 -> 268 ms; 2048^2 57.5 -> 57.3 and 1024^2 22.6 -> 23.4 ms: there each of the three kernels of a step is ONE wave of
   // workgroups whose duration does not shrink with half the pairs (Gram 12.2 -> 11.5 us, W update 16.6 -> 18.7, and the rotation kernel
   // slows from 26 to 35 us when it shares the chip), so a chain's step takes as long as the whole step did. Hence N >= 4096 only
-  // (ND4HIP_JAC_TWO_CHAINS=<min N> moves the threshold, 0 switches it off).
+  // (ND4HIP_JAC_TWO_CHAINS=<min N> moves the threshold, 0 switches it off) — and, because the deferred U update needs
+  // batch * npairs <= 64 (`defer`: N <= 4096 with 32-row blocks), in effect for padded N == 4096 alone: 8192^2 keeps one chain.
   const char* two_e = getenv("ND4HIP_JAC_TWO_CHAINS");      // (read per sweep, not cached: the tests move the threshold)
   const int two_env = two_e ? atoi(two_e) : 4096;
   const bool two_off = two_env <= 0;
