@@ -11,6 +11,8 @@
 // (v_k = 0 for k >= i, so the formulas hold for every column). Bound: HBM — 2 reads + 1 write of the active part of H
 // and of U per step; four launches per step (vector, read pass, partial reduction, update pass).
 #include "nd4hip_internal.h"
+#include "xchg.h"
+#include "dpp.h"
 #include <cstdlib>
 
 namespace {
@@ -435,6 +437,349 @@ __global__ void hess_init_u(double* __restrict__ Um, int N) {
   for (int r = blockIdx.y; r < N; r += gridDim.y) Um[base + (long)r * N + j] = (r == j) ? 1.0 : 0.0;
 }
 
+
+// ================================================================ one launch for the whole reduction (N <= 2048) ============
+// VERDICT r3 #6. The blocked form above is two DEPENDENT launches per row (18 us at 2048^2, each at the latency floor of a small
+// kernel), i.e. it is defined by its kernel boundaries. Here 16 x 16 co-resident workgroups own H as 16E x 16E tiles IN REGISTERS
+// (2048^2: 128 KB per workgroup, 64 values per thread) for all N - 2 steps; nothing of H crosses HBM between the first load and
+// the last store, so the rank-2 update of every step costs no traffic and the unblocked recurrence of hessenberg.js:27-86 is
+// used as it stands (no V / W / Y history, no GEMMs). Thread (tr, tc) of workgroup (p, q) holds rows 16E p + tr + 16 a and
+// columns 16E q + tc + 16 b. Per step two rounds of tagged words (xchg.h) cross between the workgroups, a few values per thread:
+//   B  every workgroup publishes its partials of x = H^T v (its 16E columns), y = H v (its 16E rows) and v^T H v, and the
+//      workgroups holding row i-1 publish it as it stands; workgroup (p, q) sums, in a fixed order, the 16 partials of E columns
+//      of x and of E rows of y and all 256 partials of v^T y: w = x - (v^T y) v; from y at row i-1 it also knows its E columns of
+//      row i-1 AFTER this step's update (the row the next reflector is built from) and their scaled-norm partial;
+//   C  it publishes those 3E + 2 values; (p, q) picks up w over its columns, y over its rows, the next row over both, all 256
+//      norm partials and the entry (i-1, i-2), and updates its tile. Every workgroup then builds the next v from the same scalars.
+// Tags are the row index (never repeat within a launch; the area is cleared per call), areas alternate with the parity of i; each
+// round ends with every workgroup having read something of every other, which is what keeps a fast one from overwriting an area
+// a slow one has not read yet (a skipped step — row already in Hessenberg form — therefore still runs both rounds, with zeros).
+// Every spin is bounded; a time-out raises the handle's status word and an abort flag that ends every workgroup
+// (ND4HIP_ERR_XCHG at the next synchronising call). The scalars of the reflector use the few-ulp reciprocal / reciprocal square
+// root of dpp.h: an IEEE division is ~35 dependent instructions and the chain is the step.
+struct HessPx {
+  qx_u64 *B, *C;         // [2][256][BW | CW] words: what a workgroup publishes for its row / column partners
+  qx_u64 *Bv, *Cn;       // [2][256][1 | 2] values: what every workgroup reads of every other (v^T H v partials; norm partials), contiguous
+  int* abort;            // so that a wave reads them as whole cache lines
+};
+struct HpReq { const qx_u64* slot; int v; bool on; };
+
+template <int K>
+__device__ __forceinline__ void hp_wait(const HpReq (&r)[K], double (&x)[K], unsigned tag, bool& dead, const HessPx& X, int* status) {
+  bool need[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) need[k] = r[k].on;
+  for (int n = 0; n < QX_SPIN_LIMIT; n++) {
+    bool ok = true;                                      // (only what has not arrived yet is asked for again)
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if (need[k]) {
+        bool okk = true;
+        const double v = qx_ld(r[k].slot, r[k].v, tag, okk);
+        if (okk) { x[k] = v; need[k] = false; } else ok = false;
+      }
+    if (ok) return;
+    if ((n & 255) == 255 && __hip_atomic_load(X.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; return; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  dead = true;
+  __hip_atomic_store(X.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  qx_raise(status);
+}
+
+// a + b of the partner 16 / 32 lanes away where each keeps one of two values: lanes with the bit clear end with lo(own) + lo(partner),
+// lanes with the bit set with hi(own) + hi(partner) (v_permlane{16,32}_swap exchange the odd rows / upper half of the first operand
+// with the even rows / lower half of the second)
+__device__ __forceinline__ double hp_fold16(double lo, double hi) {
+  const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(lo), __double2loint(hi), false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(lo), __double2hiint(hi), false, false);
+  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double hp_fold32(double lo, double hi) {
+  const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(lo), __double2loint(hi), false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(lo), __double2hiint(hi), false, false);
+  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, double* __restrict__ vrows, HessPx X, int* status, int drop_row, long long* stamps) {
+  using namespace nd4dpp;
+  constexpr int T = 16 * E;
+  constexpr int BW = 2 * (3 * T), CW = 2 * (3 * E);
+  constexpr int LE = E == 8 ? 3 : (E == 4 ? 2 : 1);                 // log2 E
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, tr = t >> 4, tc = t & 15;
+  const int wg = blockIdx.x, p = wg >> 4, q = wg & 15;
+  __shared__ double s_rc[T], s_rr[T], s_v[T], s_w[T], s_y[T], s_xp[4][T], s_yp[T], s_q[32 * E], s_e[16 + E];
+  __shared__ double s_wm[4], s_wS[4], s_vy[4], s_red[4], s_h0;
+  __shared__ int s_dead;
+  double h[E][E];
+#pragma unroll
+  for (int a = 0; a < E; a++)
+#pragma unroll
+    for (int b = 0; b < E; b++) {
+      const int r = T * p + tr + 16 * a, c = T * q + tc + 16 * b;
+      h[a][b] = (r < N && c < N) ? H[(long)r * N + c] : 0.0;
+    }
+  if (t == 0) s_dead = 0;
+  bool dead = false;
+  // ---- the first row (N-1) straight from memory: its slices, and the norm partials grouped exactly as the later steps group them
+  {
+    const double* row = H + (long)(N - 1) * N;
+    if (t < T) s_rc[t] = (T * q + t < N) ? row[T * q + t] : 0.0;
+    else if (t < 2 * T) s_rr[t - T] = (T * p + t - T < N) ? row[T * p + t - T] : 0.0;
+    if (t == 0) s_h0 = row[N - 2];
+    double rv[E], m = 0.0;
+#pragma unroll
+    for (int c = 0; c < E; c++) {
+      const int e = T * (t & 15) + E * (t >> 4) + c;
+      rv[c] = (e < N - 2) ? fabs(row[e]) : 0.0;
+      m = fmax(m, rv[c]);
+    }
+    double ss = 0.0;
+    const double im = m > 0.0 ? fast_rcp(m) : 0.0;
+#pragma unroll
+    for (int c = 0; c < E; c++) { const double x = rv[c] * im; ss += x * x; }
+    const double wm = wave_max(m);
+    const double f = wm > 0.0 ? m * fast_rcp(wm) : 0.0;
+    const double wS = wave_sum(ss * f * f);
+    if (lane == 0) { s_wm[wave] = wm; s_wS[wave] = wS; }
+  }
+  __syncthreads();
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? (long long)wall_clock64() : 0;   // ND4HIP_HESSP_STAMPS: time per phase (100 MHz ticks), thread 0
+#define HP_STAMP(k) if (stamps) { const long long now = (long long)wall_clock64(); tacc[k] += now - tlast; tlast = now; }
+  for (int i = N - 1; i > 1; i--) {
+    const unsigned tag = (unsigned)i;
+    const int par = i & 1, ii = i - 1;
+    const int pi = i / T, pn = ii / T, ln = ii % T;                // row block of row i; row block and local index of row i-1
+    qx_u64* bslot = X.B + ((long)par * 256 + wg) * BW;
+    // row i-1 as it stands (before this step's update), by the 16 lanes that hold it
+    if (p == pn && tr == (ln & 15) && i != drop_row) {
+#pragma unroll
+      for (int b = 0; b < E; b++) {
+        double x = 0.0;
+#pragma unroll
+        for (int a = 0; a < E; a++) if (a == (ln >> 4)) x = h[a][b];
+        qx_st(bslot, 2 * T + tc + 16 * b, x, tag);
+      }
+    }
+    // ---- the reflector's scalars (hessenberg.js:43-56), by every thread in the same order
+    const double m1 = fmax(fmax(s_wm[0], s_wm[1]), fmax(s_wm[2], s_wm[3]));
+    const bool skip = m1 == 0.0;                                  // NORM.max === 0 -> continue (:46)
+    double nrm = 0.0, vii = 0.0, inv2 = 0.0, scale = 0.0, hii = 0.0;
+    if (!skip) {
+      const double i1 = fast_rcp(m1);
+      double S1 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) { const double f = s_wm[g] * i1; S1 += s_wS[g] * f * f; }
+      const double hii0 = s_h0;
+      const double mx = fmax(m1, fabs(hii0));
+      const double imx = fast_rcp(mx);
+      const double q1 = m1 * imx, q0 = hii0 * imx;
+      const double ss = S1 * q1 * q1 + q0 * q0;
+      nrm = (isfinite(mx) ? ss * fast_rsqrt(ss) * mx : mx) * (hii0 > 0 ? -1.0 : 1.0);        // :47
+      hii = hii0 - nrm;                                                                        // :48
+      const double mx2 = fmax(m1, fabs(hii));
+      inv2 = fast_rcp(mx2);
+      const double r1 = m1 * inv2, r0 = hii * inv2;
+      scale = 1.4142135623730951 * fast_rsqrt(S1 * r1 * r1 + r0 * r0);
+      vii = hii * inv2 * scale;
+    }
+    double vr[E], vc[E];
+#pragma unroll
+    for (int a = 0; a < E; a++) {
+      const int j = T * p + tr + 16 * a;
+      vr[a] = (!skip && j < i) ? (j == ii ? vii : s_rr[tr + 16 * a] * inv2 * scale) : 0.0;       // :51-52
+    }
+#pragma unroll
+    for (int b = 0; b < E; b++) {
+      const int j = T * q + tc + 16 * b;
+      vc[b] = (!skip && j < i) ? (j == ii ? vii : s_rc[tc + 16 * b] * inv2 * scale) : 0.0;
+    }
+    if (t < T) {
+      const int j = T * q + t;
+      const double vj = (!skip && j < i) ? (j == ii ? vii : s_rc[t] * inv2 * scale) : 0.0;
+      s_v[t] = vj;
+      if (p == 0 && j < N && !skip) vrows[(long)(N - 1 - i) * N + j] = vj;          // reflector number N-1-i (processing order)
+    }
+    HP_STAMP(0)
+    // ---- B: partials of x = H^T v (rows < i: v is zero beyond), y = H v (columns < i), v^T H v
+    {
+      double xs[E], ys[E];
+#pragma unroll
+      for (int b = 0; b < E; b++) xs[b] = 0.0;
+#pragma unroll
+      for (int a = 0; a < E; a++) {
+        double y = 0.0;
+#pragma unroll
+        for (int b = 0; b < E; b++) { xs[b] = fma(vr[a], h[a][b], xs[b]); y = fma(h[a][b], vc[b], y); }
+        ys[a] = y;
+      }
+      double vy = 0.0;
+#pragma unroll
+      for (int b = 0; b < E; b++) vy = fma(xs[b], vc[b], vy);
+      vy = wave_sum(vy);
+      if (lane == 0) s_vy[wave] = vy;
+      // y: over the 16 lanes of a row of lanes; halving exchanges first (each lane ends with the row tc >> (4 - LE)), then plain ones
+      {
+        int n = E;
+        double z[E];
+#pragma unroll
+        for (int a = 0; a < E; a++) z[a] = ys[a];
+        if constexpr (E >= 2) {
+          const bool up = (tc & 8) != 0;
+#pragma unroll
+          for (int k = 0; k < E / 2; k++) { const double keep = up ? z[k + E / 2] : z[k], send = up ? z[k] : z[k + E / 2]; z[k] = keep + xor8(send); }
+          n = E / 2;
+        }
+        if constexpr (E >= 4) {
+          const bool up = (tc & 4) != 0;
+#pragma unroll
+          for (int k = 0; k < E / 4; k++) { const double keep = up ? z[k + E / 4] : z[k], send = up ? z[k] : z[k + E / 4]; z[k] = keep + xor4(send); }
+          n = E / 4;
+        } else z[0] += xor4(z[0]);
+        if constexpr (E >= 8) {
+          const bool up = (tc & 2) != 0;
+          const double keep = up ? z[1] : z[0], send = up ? z[0] : z[1];
+          z[0] = keep + xor2(send);
+        } else z[0] += xor2(z[0]);
+        z[0] += xor1(z[0]);
+        (void)n;
+        if ((tc & ((16 >> LE) - 1)) == 0) s_yp[tr + 16 * (tc >> (4 - LE))] = z[0];
+      }
+      // x: over the 4 lane rows of the wave (then over the waves through LDS)
+      if constexpr (E == 8) {
+        double z[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) z[k] = hp_fold16(xs[k], xs[k + 4]);
+        const double z0 = hp_fold32(z[0], z[2]), z1 = hp_fold32(z[1], z[3]);
+        const int b0 = 4 * (tr & 1) + 2 * ((tr >> 1) & 1);
+        s_xp[wave][tc + 16 * b0] = z0; s_xp[wave][tc + 16 * (b0 + 1)] = z1;
+      } else if constexpr (E == 4) {
+        const double z0 = hp_fold16(xs[0], xs[2]), z1 = hp_fold16(xs[1], xs[3]);
+        const double zz = hp_fold32(z0, z1);
+        s_xp[wave][tc + 16 * (2 * (tr & 1) + ((tr >> 1) & 1))] = zz;
+      } else {
+        const double z0 = hp_fold16(xs[0], xs[1]);
+        const double zz = hp_fold32(z0, z0);
+        if (lane < 32) s_xp[wave][tc + 16 * (tr & 1)] = zz;
+      }
+    }
+    __syncthreads();
+    HP_STAMP(1)
+    if (t < T) qx_st(bslot, t, skip ? 0.0 : (s_xp[0][t] + s_xp[1][t]) + (s_xp[2][t] + s_xp[3][t]), tag);
+    else if (t < 2 * T) qx_st(bslot, t, skip ? 0.0 : s_yp[t - T], tag);
+    if (t == 0) qx_st(X.Bv + (long)par * 512, wg, skip ? 0.0 : (s_vy[0] + s_vy[1]) + (s_vy[2] + s_vy[3]), tag);
+    // the 16 partials of this workgroup's E columns of x and E rows of y, all 256 partials of v^T y, the 16 partials of y at row
+    // i-1 and this workgroup's E columns of row i-1
+    {
+      HpReq rq[3];
+      double xv[3] = {0.0, 0.0, 0.0};
+      const qx_u64* Bp = X.B + (long)par * 256 * BW;
+      if (t < 16 * E) rq[0] = HpReq{Bp + (long)((t / E) * 16 + q) * BW, E * p + t % E, true};
+      else { const int u = t - 16 * E; rq[0] = HpReq{Bp + (long)(p * 16 + u / E) * BW, T + E * q + u % E, t < 32 * E}; }
+      rq[1] = HpReq{X.Bv + (long)par * 512, t, true};
+      if (t < 16) rq[2] = HpReq{Bp + (long)(pn * 16 + t) * BW, T + ln, true};
+      else rq[2] = HpReq{Bp + (long)(pn * 16 + q) * BW, 2 * T + E * p + (t - 16), t < 16 + E};
+      hp_wait<3>(rq, xv, tag, dead, X, status);
+      if (t < 32 * E) s_q[t] = xv[0];
+      if (t < 16 + E) s_e[t] = xv[2];
+      const double vys = wave_sum(xv[1]);
+      if (lane == 0) s_red[wave] = vys;
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    HP_STAMP(2)
+    if (t < 2 * E) {
+      const int c = t < E ? t : t - E;
+      double s = 0.0;
+#pragma unroll
+      for (int pp = 0; pp < 16; pp++) s += s_q[(t < E ? 0 : 16 * E) + pp * E + c];
+      qx_u64* cslot = X.C + ((long)par * 256 + wg) * CW;
+      if (t < E) {
+        const double vy = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        const double ve = s_v[E * p + c];
+        const double w = s - vy * ve;                                       // w = x - (v^T y) v
+        double yn = 0.0;                                                    // y at row i-1, summed as its owner sums it
+#pragma unroll
+        for (int pp = 0; pp < 16; pp++) yn += s_e[pp];
+        const double rn = fma(-vii, w, fma(-yn, ve, s_e[16 + c]));         // row i-1 after this step's update, as the tile computes it
+        const int e = T * q + E * p + c;
+        double am = (e < ii - 1) ? fabs(rn) : 0.0, m = am;                  // the next step scans the columns < i-2
+        if constexpr (E >= 2) m = fmax(m, xor1(m));
+        if constexpr (E >= 4) m = fmax(m, xor2(m));
+        if constexpr (E >= 8) m = fmax(m, xor4(m));
+        const double x = m > 0.0 ? am * fast_rcp(m) : 0.0;
+        double ss = x * x;
+        if constexpr (E >= 2) ss += xor1(ss);
+        if constexpr (E >= 4) ss += xor2(ss);
+        if constexpr (E >= 8) ss += xor4(ss);
+        qx_st(cslot, c, w, tag);
+        qx_st(cslot, 2 * E + c, rn, tag);
+        if (c == 0) { qx_st(X.Cn + (long)par * 1024, 2 * wg, m, tag); qx_st(X.Cn + (long)par * 1024, 2 * wg + 1, ss, tag); }
+      } else {
+        qx_st(cslot, E + c, (T * p + E * q + c < i) ? s : 0.0, tag);      // y, rows < i only
+      }
+    }
+    // ---- C: w over the columns q, y over the rows p, the next row over both, the norm partials, the entry (i-1, i-2)
+    {
+      HpReq rq[5];
+      double xv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      const qx_u64* Cp = X.C + (long)par * 256 * CW;
+      if (t < T) {
+        const qx_u64* s = Cp + (long)((t / E) * 16 + q) * CW;
+        rq[0] = HpReq{s, t % E, true}; rq[1] = HpReq{s, 2 * E + t % E, true};
+      } else {
+        const int j = t - T;
+        rq[0] = HpReq{Cp + (long)(p * 16 + j / E) * CW, E + j % E, t < 2 * T};
+        rq[1] = HpReq{Cp + (long)((j / E) * 16 + p) * CW, 2 * E + j % E, t < 2 * T};
+      }
+      rq[2] = HpReq{X.Cn + (long)par * 1024, 2 * t, true};
+      rq[3] = HpReq{X.Cn + (long)par * 1024, 2 * t + 1, true};
+      { const int e = ii - 1 < 0 ? 0 : ii - 1, j = e % T; rq[4] = HpReq{Cp + (long)((j / E) * 16 + e / T) * CW, 2 * E + j % E, t == 0}; }
+      hp_wait<5>(rq, xv, tag, dead, X, status);
+      if (t < T) { s_w[t] = xv[0]; s_rc[t] = xv[1]; }
+      else if (t < 2 * T) { s_y[t - T] = xv[0]; s_rr[t - T] = xv[1]; }
+      if (t == 0) s_h0 = xv[4];
+      const double wm = wave_max(xv[2]);
+      const double f = wm > 0.0 ? xv[2] * fast_rcp(wm) : 0.0;
+      const double wS = wave_sum(xv[3] * f * f);
+      if (lane == 0) { s_wm[wave] = wm; s_wS[wave] = wS; }
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    HP_STAMP(3)
+    if (!skip) {
+#pragma unroll
+      for (int a = 0; a < E; a++) {
+        const double ya = s_y[tr + 16 * a];
+#pragma unroll
+        for (int b = 0; b < E; b++) h[a][b] = fma(-vr[a], s_w[tc + 16 * b], fma(-ya, vc[b], h[a][b]));
+      }
+      if (p == pi) {                                                       // the finished row (:83-84)
+#pragma unroll
+        for (int a = 0; a < E; a++)
+#pragma unroll
+          for (int b = 0; b < E; b++) {
+            const int r = T * p + tr + 16 * a, c = T * q + tc + 16 * b;
+            if (r == i) { if (c < ii) h[a][b] = 0.0; else if (c == ii) h[a][b] = nrm; }
+          }
+      }
+    }
+    HP_STAMP(4)
+  }
+#undef HP_STAMP
+  if (stamps && t == 0) for (int k = 0; k < 5; k++) stamps[wg * 8 + k] = tacc[k];
+#pragma unroll
+  for (int a = 0; a < E; a++)
+#pragma unroll
+    for (int b = 0; b < E; b++) {
+      const int r = T * p + tr + 16 * a, c = T * q + tc + 16 * b;
+      if (r < N && c < N) H[(long)r * N + c] = h[a][b];
+    }
+}
+
 }  // namespace
 
 // A [batch, N, N] -> U, H [batch, N, N]
@@ -471,7 +816,39 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
   }
   const int cchunks = (N + 255) / 256;
   const bool blocked_path = wy && batch == 1 && N >= 512 && (N & 1) == 0 && (size_t)N * sizeof(double) <= 48 * 1024 && !getenv("ND4HIP_HESS_UNBLOCKED");
-  if (blocked_path) {
+  static const bool no_persist = getenv("ND4HIP_HESS_NO_PERSIST") != nullptr;
+  const bool persist = wy && batch == 1 && N >= 128 && N <= 2048 && !no_persist && !getenv("ND4HIP_HESS_UNBLOCKED");
+  if (persist) {
+    // ---- one launch: 16 x 16 workgroups keep H in registers for the whole reduction (see hessp) ----
+    const int E = N <= 512 ? 2 : (N <= 1024 ? 4 : 8), T = 16 * E;
+    const size_t BW = 2 * (3 * T), CW = 2 * (3 * E);
+    const size_t xwords = 2 * 256 * (BW + CW) + 2 * 512 + 2 * 1024;
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, &q));
+    double* vrows = static_cast<double*>(q);
+    HessPx X;
+    X.B = reinterpret_cast<qx_u64*>(vrows + (size_t)nstore * N); X.C = X.B + 2 * 256 * BW;
+    X.Bv = X.C + 2 * 256 * CW; X.Cn = X.Bv + 2 * 512;
+    X.abort = reinterpret_cast<int*>(X.Cn + 2 * 1024);
+    ND4_HIP(hipMemsetAsync(vrows, 0, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, h->stream));
+    const int drop = nd4_test_drop_panel() >= 0 ? N - 1 - nd4_test_drop_panel() : -1;       // test hook: row N-1-k is never published
+    static const bool want_stamps = getenv("ND4HIP_HESSP_STAMPS") != nullptr;
+    long long* stamps = nullptr;
+    if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
+    if (E == 2) hipLaunchKernelGGL(hessp<2>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
+    else if (E == 4) hipLaunchKernelGGL(hessp<4>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
+    else hipLaunchKernelGGL(hessp<8>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
+    ND4_HIP(hipGetLastError());
+    if (stamps) {                                     // per step, in us: reflector | products | B | sums + C | update
+      long long hs[256 * 8];
+      ND4_HIP(hipMemcpyAsync(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+      ND4_HIP(hipStreamSynchronize(h->stream));
+      for (int g : {0, 17, 119, 255})
+        fprintf(stderr, "hessp N=%d wg %3d: scalars+v %.2f  matvec %.2f  B %.2f  C %.2f  update %.2f us per step\n", N, g,
+                hs[g * 8] * 0.01 / (N - 2), hs[g * 8 + 1] * 0.01 / (N - 2), hs[g * 8 + 2] * 0.01 / (N - 2), hs[g * 8 + 3] * 0.01 / (N - 2), hs[g * 8 + 4] * 0.01 / (N - 2));
+    }
+    ND4_TRY(nd4_transpose(h, nstore, N, vrows, N, ws.vstore, nstore, 1, 0, 0));            // reflectors as columns for nd4_wy_form
+  } else if (blocked_path) {
     // ---- blocked: NBH steps per block, H untouched inside a block, two GEMMs per block ----
     const int nchunks = (N + BC - 1) / BC;
     void* q = nullptr;
