@@ -17,6 +17,9 @@
 // U and V are formed afterwards from the stored reflectors: at once from their compact-WY form (nd4_wy_form: one big matrix)
 // or by applying them backwards to the identity (batches of small matrices).
 #include "nd4hip_internal.h"
+#include "xchg16.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -433,6 +436,339 @@ __global__ void bd2_finish_row(double* __restrict__ W, int N, int i, const doubl
   if (c < N) W[(long)i * N + c] = rowfin[c];
 }
 
+// ================================================================ one launch for the whole reduction (M, N <= 2048) =========
+// VERDICT r3 #6, second half (hess.hip: hessp has the first). The fused form above is two DEPENDENT launches per step (29 us at
+// 2048^2). Here 16 x 16 co-resident workgroups keep the matrix as 16E x 16E tiles IN REGISTERS for all K steps (thread (tr, tc) of
+// workgroup (p, q): rows 16E p + tr + 16 a, columns 16E q + tc + 16 b), the rank-2 update of a step costs no traffic, and a step is
+// four rounds of 16-byte tagged pairs (xchg16.h) — the two matrix-vector products of a step depend on each other (v is built from
+// row i AFTER the left reflector), so each needs its own reduce and broadcast:
+//   1  every workgroup publishes its partial of u^T A over its 16E columns (and, where it holds them, row i and column i+1 as they
+//      stand); workgroup (p, q) sums the 16 partials of E columns in a fixed order: z = tau u^T A, r = A[i,:] - z, and the scaled
+//      norm partial and z.r partial of its columns > i+1;
+//   2  it publishes z, r over its columns (+ the three partials, read by everybody): every workgroup builds the right reflector v
+//      (reference convention, bidiag.js:66-76) from the same scalars, and knows z.v;
+//   3  every workgroup publishes its partial of A v over its 16E rows; (p, q) sums the 16 partials of E rows: y = 2 (A v - u (z.v)),
+//      column i+1 after this step's update at its rows (the next left reflector is built from it) and its scaled norm partial;
+//   4  it publishes those; every workgroup picks up y and the next column over its rows and all norm partials, updates its tile
+//      (A -= u z^T + y v^T) and builds the next u, tau from the same scalars.
+// Only the two diagonals of B, the reflectors and tau leave the kernel. Tags are the step + 1, areas alternate with the parity of
+// the step; rounds 2 and 4 end with every workgroup having read something of every other, so no area is overwritten before it
+// has been read. Every spin is bounded (time-out: abort flag for all workgroups, ND4HIP_ERR_XCHG at the next synchronising call).
+struct BdPx {
+  qx_u64* base;
+  unsigned o1, o2, o3, o4;   // [2][256][3T | 2E | T | 2E] values (byte offsets)
+  unsigned oA2, oA4;         // [2][256][3 | 2] values read by everybody
+  unsigned bytes;
+  int* abort;
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N, int K, double* __restrict__ ULt, double* __restrict__ tauL,
+                                            double* __restrict__ VR, int* __restrict__ flagR, BdPx X, int* status, int delay, long long* stamps) {
+  using namespace nd4dpp;
+  constexpr int T = 16 * E, V1 = 3 * T, V2 = 2 * E, V3 = T, V4 = 2 * E;
+  constexpr int LE = E == 8 ? 3 : (E == 4 ? 2 : 1);                 // log2 E
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, tr = t >> 4, tc = t & 15;
+  const int wg = blockIdx.x, p = wg >> 4, q = wg & 15;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X.base, 0, (int)X.bytes, 0x00020000);
+  __shared__ double s_cu[T], s_u[T], s_z[T], s_r[T], s_y[T], s_xp[4][T], s_yp[T], s_q[17 * E];
+  __shared__ double s_wm[4], s_wS[4], s_rm[4], s_rS[4], s_rZ[4], s_alpha, s_x0, s_z0;
+  __shared__ int s_dead;
+  double a[E][E];
+#pragma unroll
+  for (int ai = 0; ai < E; ai++)
+#pragma unroll
+    for (int bi = 0; bi < E; bi++) {
+      const int r = T * p + tr + 16 * ai, c = T * q + tc + 16 * bi;
+      a[ai][bi] = (r < M && c < N) ? W[(long)r * N + c] : 0.0;
+    }
+  if (t == 0) s_dead = 0;
+  bool dead = false;
+  // ---- column 0 straight from memory: its slice over the rows p, and the norm partials grouped as round 3 groups them
+  {
+    if (t < T) s_cu[t] = (T * p + t < M) ? W[(long)(T * p + t) * N] : 0.0;
+    if (t == 0) s_alpha = W[0];
+    double rv[E], m = 0.0;
+#pragma unroll
+    for (int c = 0; c < E; c++) {
+      const int e = T * (t >> 4) + E * (t & 15) + c;
+      rv[c] = (e > 0 && e < M) ? fabs(W[(long)e * N]) : 0.0;
+      m = fmax(m, rv[c]);
+    }
+    double ss = 0.0;
+    const double im = m > 0.0 ? fast_rcp(m) : 0.0;
+#pragma unroll
+    for (int c = 0; c < E; c++) { const double x = rv[c] * im; ss += x * x; }
+    const double wm = wave_max(m);
+    const double f = wm > 0.0 ? m * fast_rcp(wm) : 0.0;
+    const double wS = wave_sum(ss * f * f);
+    if (lane == 0) { s_wm[wave] = wm; s_wS[wave] = wS; }
+  }
+  __syncthreads();
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamps ? (long long)wall_clock64() : 0;   // ND4HIP_BDP_STAMPS: time per phase (100 MHz ticks)
+#define BP_STAMP(k) if (stamps) { const long long now = (long long)wall_clock64(); tacc[k] += now - tlast; tlast = now; }
+  for (int i = 0; i < K; i++) {
+    const unsigned tag = (unsigned)i + 1;
+    const int par = i & 1, first = i + 1;
+    const int pi = i / T, li = i % T, q1 = first / T, l1 = first % T;
+    const bool more = first < K;
+    const unsigned R1p = X.o1 + (unsigned)par * 256 * V1 * 16, R2p = X.o2 + (unsigned)par * 256 * V2 * 16;
+    const unsigned R3p = X.o3 + (unsigned)par * 256 * V3 * 16, R4p = X.o4 + (unsigned)par * 256 * V4 * 16;
+    const unsigned A2p = X.oA2 + (unsigned)par * 256 * 3 * 16, A4p = X.oA4 + (unsigned)par * 256 * 2 * 16;
+    const unsigned slot1 = R1p + (unsigned)wg * V1 * 16;
+    // row i and column i+1 as they stand, by the lanes that hold them
+    if (p == pi && tr == (li & 15)) {
+#pragma unroll
+      for (int bi = 0; bi < E; bi++) {
+        double x = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < E; ai++) if (ai == (li >> 4)) x = a[ai][bi];
+        hp_st(rs, slot1 + (T + tc + 16 * bi) * 16, x, tag);
+      }
+    }
+    if (more && q == q1 && tc == (l1 & 15)) {
+#pragma unroll
+      for (int ai = 0; ai < E; ai++) {
+        double x = 0.0;
+#pragma unroll
+        for (int bi = 0; bi < E; bi++) if (bi == (l1 >> 4)) x = a[ai][bi];
+        hp_st(rs, slot1 + (2 * T + tr + 16 * ai) * 16, x, tag);
+      }
+    }
+    // ---- the left reflector's scalars (LAPACK dlarfg with a max-scaled norm, as bd_vec_col), by every thread in the same order
+    const double cmx = fmax(fmax(s_wm[0], s_wm[1]), fmax(s_wm[2], s_wm[3]));
+    const double alpha = s_alpha;
+    double tau = 0.0, inv = 0.0, dI = alpha;
+    if (cmx != 0.0) {
+      const double i1 = fast_rcp(cmx);
+      double S = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) { const double f = s_wm[g] * i1; S += s_wS[g] * f * f; }
+      const double sc = fmax(cmx, fabs(alpha));
+      const double isc = fast_rcp(sc);
+      const double a1 = alpha * isc, c1 = cmx * isc;
+      const double t2 = S * c1 * c1 + a1 * a1;
+      const double nrm = t2 * fast_rsqrt(t2) * sc;
+      const double beta = alpha > 0 ? -nrm : nrm;
+      tau = (beta - alpha) * fast_rcp(beta);
+      inv = fast_rcp(alpha - beta);
+      dI = beta;
+    }
+    double ur[E];
+#pragma unroll
+    for (int ai = 0; ai < E; ai++) {
+      const int r = T * p + tr + 16 * ai;
+      ur[ai] = r < i ? 0.0 : (r == i ? 1.0 : s_cu[tr + 16 * ai] * inv);
+    }
+    if (t < T) {
+      const int r = T * p + t;
+      const double u = r < i ? 0.0 : (r == i ? 1.0 : s_cu[t] * inv);
+      s_u[t] = u;
+      if (q == 0 && r < M) ULt[(long)i * M + r] = u;
+    }
+    BP_STAMP(0)
+    // ---- round 1: partials of u^T A over the rows p
+    {
+      double zs[E];
+#pragma unroll
+      for (int bi = 0; bi < E; bi++) zs[bi] = 0.0;
+#pragma unroll
+      for (int ai = 0; ai < E; ai++)
+#pragma unroll
+        for (int bi = 0; bi < E; bi++) zs[bi] = fma(ur[ai], a[ai][bi], zs[bi]);
+      hp_sum_over_tr<E>(zs, tr, tc, lane, s_xp[wave]);
+    }
+    __syncthreads();
+    if (t < T) hp_st(rs, slot1 + t * 16, (s_xp[0][t] + s_xp[1][t]) + (s_xp[2][t] + s_xp[3][t]), tag);
+    {
+      HpReq rq[2];
+      double xv[2] = {0.0, 0.0};
+      rq[0] = HpReq{R1p + (unsigned)((((t / E) & 15) * 16 + q) * V1 + E * p + t % E) * 16, t < 16 * E};
+      rq[1] = HpReq{R1p + (unsigned)((pi * 16 + q) * V1 + T + E * p + (t % E)) * 16, t < E};
+      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      if (t < 16 * E) s_q[t] = xv[0];
+      if (t < E) s_q[16 * E + t] = xv[1];
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    BP_STAMP(1)
+    if (t < E) {
+      const int c = t, e = T * q + E * p + c;
+      double s = 0.0;
+#pragma unroll
+      for (int pp = 0; pp < 16; pp++) s += s_q[pp * E + c];
+      const double z = (e > i && e < N) ? tau * s : 0.0;
+      const double r = (e > i && e < N) ? s_q[16 * E + c] - z : 0.0;                 // u_i = 1
+      const double am = (e > first) ? fabs(r) : 0.0;
+      double m = am;
+      if constexpr (E >= 2) m = fmax(m, xor1(m));
+      if constexpr (E >= 4) m = fmax(m, xor2(m));
+      if constexpr (E >= 8) m = fmax(m, xor4(m));
+      const double im = m > 0.0 ? fast_rcp(m) : 0.0;
+      const double x = am * im;
+      double ss = x * x, zr = (e > first) ? z * (r * im) : 0.0;
+      if constexpr (E >= 2) { ss += xor1(ss); zr += xor1(zr); }
+      if constexpr (E >= 4) { ss += xor2(ss); zr += xor2(zr); }
+      if constexpr (E >= 8) { ss += xor4(ss); zr += xor4(zr); }
+      const unsigned slot2 = R2p + (unsigned)wg * V2 * 16;
+      hp_st(rs, slot2 + c * 16, z, tag);
+      hp_st(rs, slot2 + (E + c) * 16, r, tag);
+      if (c == 0) { hp_st(rs, A2p + (wg * 3) * 16, m, tag); hp_st(rs, A2p + (wg * 3 + 1) * 16, ss, tag); hp_st(rs, A2p + (wg * 3 + 2) * 16, zr, tag); }
+    }
+    // ---- round 2: z and r over the columns q, the partials of everybody, the entries at column i+1
+    {
+      HpReq rq[7];
+      double xv[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const unsigned src = R2p + (unsigned)((((t / E) & 15) * 16 + q) * V2) * 16;
+      rq[0] = HpReq{src + (t % E) * 16, t < T};
+      rq[1] = HpReq{src + (E + t % E) * 16, t < T};
+      rq[2] = HpReq{A2p + (unsigned)(t * 3) * 16, true};
+      rq[3] = HpReq{A2p + (unsigned)(t * 3 + 1) * 16, true};
+      rq[4] = HpReq{A2p + (unsigned)(t * 3 + 2) * 16, true};
+      const int ef = first < N ? first : i, jf = ef % T;
+      const unsigned srcf = R2p + (unsigned)(((jf / E) * 16 + ef / T) * V2) * 16;
+      rq[5] = HpReq{srcf + (E + jf % E) * 16, t == 0};
+      rq[6] = HpReq{srcf + (jf % E) * 16, t == 0};
+      hp_wait<7>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      if (t < T) { s_z[t] = xv[0]; s_r[t] = xv[1]; }
+      if (t == 0) { s_x0 = xv[5]; s_z0 = xv[6]; }
+      const double wm = wave_max(xv[2]);
+      const double f = wm > 0.0 ? xv[2] * fast_rcp(wm) : 0.0;
+      const double wS = wave_sum(xv[3] * f * f), wZ = wave_sum(xv[4] * f);
+      if (lane == 0) { s_rm[wave] = wm; s_rS[wave] = wS; s_rZ[wave] = wZ; }
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    BP_STAMP(2)
+    // ---- the right reflector's scalars (bidiag.js:66-76: norm = -sign(x_first) |x|, v = (x - norm e) / max / sqrt(sum), H = I - 2 v v^T)
+    const double m1 = fmax(fmax(s_rm[0], s_rm[1]), fmax(s_rm[2], s_rm[3]));
+    const bool skipR = !(first < N - 1) || m1 == 0.0;              // NORM.max === 0 -> continue (bidiag.js:67)
+    const double x0 = s_x0, z0 = s_z0;
+    double nrmR = 0.0, vfirst = 0.0, fvr = 0.0, zv = 0.0;
+    if (!skipR) {
+      const double i1 = fast_rcp(m1);
+      double S1 = 0.0, Z1 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) { const double f = s_rm[g] * i1; S1 += s_rS[g] * f * f; Z1 += s_rZ[g] * f; }
+      const double mx = fmax(m1, fabs(x0));
+      const double imx = fast_rcp(mx);
+      const double c1 = m1 * imx, c0 = x0 * imx;
+      const double ss = S1 * c1 * c1 + c0 * c0;
+      nrmR = (isfinite(mx) ? ss * fast_rsqrt(ss) * mx : mx) * (x0 > 0 ? -1.0 : 1.0);
+      const double head = x0 - nrmR;
+      const double mx2 = fmax(m1, fabs(head));
+      const double inv2 = fast_rcp(mx2);
+      const double r1 = m1 * inv2, r0 = head * inv2;
+      const double rdiv = fast_rsqrt(S1 * r1 * r1 + r0 * r0);
+      fvr = inv2 * rdiv;
+      vfirst = r0 * rdiv;
+      zv = (z0 * r0 + Z1 * r1) * rdiv;                               // sum over j >= i+1 of z_j v_j
+    }
+    double vc[E], zc[E];
+#pragma unroll
+    for (int bi = 0; bi < E; bi++) {
+      const int c = T * q + tc + 16 * bi;
+      vc[bi] = (!skipR && c >= first && c < N) ? (c == first ? vfirst : s_r[tc + 16 * bi] * fvr) : 0.0;
+      zc[bi] = s_z[tc + 16 * bi];
+    }
+    if (t < T && p == 0 && !skipR) {
+      const int c = T * q + t;
+      if (c < N) VR[(long)i * N + c] = c >= first ? (c == first ? vfirst : s_r[t] * fvr) : 0.0;
+    }
+    if (wg == 0 && t == 0) {
+      W[(long)i * N + i] = dI;
+      if (first < N) W[(long)i * N + first] = skipR ? x0 : nrmR;
+      tauL[i] = tau; flagR[i] = skipR ? 0 : 1;
+    }
+    if (!more) break;
+    BP_STAMP(3)
+    // ---- round 3: partials of A v over the columns q
+    {
+      double ys[E];
+#pragma unroll
+      for (int ai = 0; ai < E; ai++) {
+        double y = 0.0;
+#pragma unroll
+        for (int bi = 0; bi < E; bi++) y = fma(a[ai][bi], vc[bi], y);
+        ys[ai] = y;
+      }
+      const double ysum = hp_sum_over_tc<E>(ys, tc);
+      if ((tc & ((16 >> LE) - 1)) == 0) s_yp[tr + 16 * (tc >> (4 - LE))] = ysum;
+    }
+    __syncthreads();
+    if (t < T) hp_st(rs, R3p + (unsigned)(wg * V3 + t) * 16, skipR ? 0.0 : s_yp[t], tag);
+    {
+      HpReq rq[2];
+      double xv[2] = {0.0, 0.0};
+      rq[0] = HpReq{R3p + (unsigned)((p * 16 + ((t / E) & 15)) * V3 + E * q + t % E) * 16, t < 16 * E};
+      rq[1] = HpReq{R1p + (unsigned)((p * 16 + q1) * V1 + 2 * T + E * q + (t % E)) * 16, t < E};
+      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      if (t < 16 * E) s_q[t] = xv[0];
+      if (t < E) s_q[16 * E + t] = xv[1];
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    BP_STAMP(4)
+    if (t < E) {
+      const int c = t, e = T * p + E * q + c;
+      double s = 0.0;
+#pragma unroll
+      for (int pp = 0; pp < 16; pp++) s += s_q[pp * E + c];
+      const double ue = s_u[E * q + c];
+      const double y = (e > i && e < M) ? 2.0 * (s - ue * zv) : 0.0;
+      const double cn = (e > i && e < M) ? fma(-y, vfirst, fma(-ue, z0, s_q[16 * E + c])) : 0.0;   // column i+1 as the tile will hold it
+      const double am = (e > first) ? fabs(cn) : 0.0;
+      double m = am;
+      if constexpr (E >= 2) m = fmax(m, xor1(m));
+      if constexpr (E >= 4) m = fmax(m, xor2(m));
+      if constexpr (E >= 8) m = fmax(m, xor4(m));
+      const double x = m > 0.0 ? am * fast_rcp(m) : 0.0;
+      double ss = x * x;
+      if constexpr (E >= 2) ss += xor1(ss);
+      if constexpr (E >= 4) ss += xor2(ss);
+      if constexpr (E >= 8) ss += xor4(ss);
+      const unsigned slot4 = R4p + (unsigned)wg * V4 * 16;
+      hp_st(rs, slot4 + c * 16, y, tag);
+      hp_st(rs, slot4 + (E + c) * 16, cn, tag);
+      if (c == 0) { hp_st(rs, A4p + (wg * 2) * 16, m, tag); hp_st(rs, A4p + (wg * 2 + 1) * 16, ss, tag); }
+    }
+    // ---- round 4: y and the next column over the rows p, the norm partials of everybody, the next diagonal entry
+    {
+      HpReq rq[5];
+      double xv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      const unsigned src = R4p + (unsigned)((p * 16 + ((t / E) & 15)) * V4) * 16;
+      rq[0] = HpReq{src + (t % E) * 16, t < T};
+      rq[1] = HpReq{src + (E + t % E) * 16, t < T};
+      rq[2] = HpReq{A4p + (unsigned)(t * 2) * 16, true};
+      rq[3] = HpReq{A4p + (unsigned)(t * 2 + 1) * 16, true};
+      rq[4] = HpReq{R4p + (unsigned)((q1 * 16 + l1 / E) * V4 + E + l1 % E) * 16, t == 0};       // row i+1: block q1, local l1
+      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      if (t < T) { s_y[t] = xv[0]; s_cu[t] = xv[1]; }
+      if (t == 0) s_alpha = xv[4];
+      const double wm = wave_max(xv[2]);
+      const double f = wm > 0.0 ? xv[2] * fast_rcp(wm) : 0.0;
+      const double wS = wave_sum(xv[3] * f * f);
+      if (lane == 0) { s_wm[wave] = wm; s_wS[wave] = wS; }
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();
+    if (s_dead) break;
+    BP_STAMP(5)
+#pragma unroll
+    for (int ai = 0; ai < E; ai++) {
+      const double ya = s_y[tr + 16 * ai];
+#pragma unroll
+      for (int bi = 0; bi < E; bi++) a[ai][bi] = fma(-ya, vc[bi], fma(-ur[ai], zc[bi], a[ai][bi]));
+    }
+    BP_STAMP(6)
+  }
+#undef BP_STAMP
+  if (stamps && t == 0) for (int k = 0; k < 7; k++) stamps[wg * 8 + k] = tacc[k];
+}
+
 struct BdWs { double* z; double* y; double* zpart; long sV, sZ; int ncols_total; };
 
 // X[r0:r1, c0:c1] -= a * (scale * a^T X): a = column acol of A2 (ld lda); gate = tau array (scale and on/off switch)
@@ -490,7 +826,41 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
 
   // ---- factorisation ----
   static const bool fused_off = getenv("ND4HIP_BIDIAG_UNFUSED") != nullptr;          // A/B switch
-  if (!fused_off && batch == 1 && M >= 128 && N >= 128 && M <= BD2_MAXM && N <= BD2_MAXN) {
+  static const bool no_persist = getenv("ND4HIP_BIDIAG_NO_PERSIST") != nullptr;
+  if (!fused_off && !no_persist && batch == 1 && M >= 128 && N >= 128 && M <= 2048 && N <= 2048) {
+    // ---- one launch: 16 x 16 workgroups keep the matrix in registers for the whole reduction (see bdp) ----
+    const int E = mx <= 512 ? 2 : (mx <= 1024 ? 4 : 8), T = 16 * E;
+    const size_t V1 = 3 * T, V2 = 2 * E, V3 = T, V4 = 2 * E;
+    const size_t xbytes = 16 * 2 * 256 * (V1 + V2 + V3 + V4 + 3 + 2);
+    Nd4WsScope scope2(h);
+    void* qp = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)K * M + xbytes + 64, &qp));
+    double* ULt = static_cast<double*>(qp);                  // [K][M]: reflector i as a row (transposed into UL at the end)
+    BdPx X;
+    X.base = reinterpret_cast<qx_u64*>(ULt + (size_t)K * M);
+    X.o1 = 0; X.o2 = X.o1 + (unsigned)(2 * 256 * V1 * 16); X.o3 = X.o2 + (unsigned)(2 * 256 * V2 * 16); X.o4 = X.o3 + (unsigned)(2 * 256 * V3 * 16);
+    X.oA2 = X.o4 + (unsigned)(2 * 256 * V4 * 16); X.oA4 = X.oA2 + 2 * 256 * 3 * 16; X.bytes = X.oA4 + 2 * 256 * 2 * 16;
+    X.abort = reinterpret_cast<int*>(reinterpret_cast<char*>(X.base) + xbytes);
+    ND4_HIP(hipMemsetAsync(X.base, 0, xbytes + 64, h->stream));
+    static const bool want_stamps = getenv("ND4HIP_BDP_STAMPS") != nullptr;
+    const int delay = getenv("ND4HIP_BDP_DELAY") ? atoi(getenv("ND4HIP_BDP_DELAY")) : 4;         // s_sleep(8) units before the first look of a round
+    long long* stamps = nullptr;
+    if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
+    if (E == 2) hipLaunchKernelGGL(bdp<2>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
+    else if (E == 4) hipLaunchKernelGGL(bdp<4>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
+    else hipLaunchKernelGGL(bdp<8>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
+    ND4_HIP(hipGetLastError());
+    if (stamps) {                                     // per step, in us: left reflector | round 1 | sums + round 2 | right reflector | round 3 | sums + round 4 | update
+      long long hs[256 * 8];
+      ND4_HIP(hipMemcpyAsync(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost, h->stream));
+      ND4_HIP(hipStreamSynchronize(h->stream));
+      for (int g : {0, 119, 255})
+        fprintf(stderr, "bdp %dx%d wg %3d: left %.2f  r1 %.2f  r2 %.2f  right %.2f  r3 %.2f  r4 %.2f  update %.2f us per step\n", M, N, g,
+                hs[g * 8] * 0.01 / K, hs[g * 8 + 1] * 0.01 / K, hs[g * 8 + 2] * 0.01 / K, hs[g * 8 + 3] * 0.01 / K, hs[g * 8 + 4] * 0.01 / K,
+                hs[g * 8 + 5] * 0.01 / K, hs[g * 8 + 6] * 0.01 / K);
+    }
+    ND4_TRY(nd4_transpose(h, K, M, ULt, M, UL, K, 1, 0, 0));
+  } else if (!fused_off && batch == 1 && M >= 128 && N >= 128 && M <= BD2_MAXM && N <= BD2_MAXN) {
     double* ucol = ws.zpart;                                 // M doubles (the partial sums of the unfused form are not needed)
     double* rowfin = ucol + mx;                              // N doubles
     double* ubuf[2] = {rowfin + mx, rowfin + 2 * mx};        // contiguous u of the previous / the current step

@@ -11,7 +11,7 @@
 // (v_k = 0 for k >= i, so the formulas hold for every column). Bound: HBM — 2 reads + 1 write of the active part of H
 // and of U per step; four launches per step (vector, read pass, partial reduction, update pass).
 #include "nd4hip_internal.h"
-#include "xchg.h"
+#include "xchg16.h"
 #include "dpp.h"
 #include <cstdlib>
 
@@ -458,57 +458,21 @@ __global__ void hess_init_u(double* __restrict__ Um, int N) {
 // (ND4HIP_ERR_XCHG at the next synchronising call). The scalars of the reflector use the few-ulp reciprocal / reciprocal square
 // root of dpp.h: an IEEE division is ~35 dependent instructions and the chain is the step.
 struct HessPx {
-  qx_u64 *B, *C;         // [2][256][BW | CW] words: what a workgroup publishes for its row / column partners
-  qx_u64 *Bv, *Cn;       // [2][256][1 | 2] values: what every workgroup reads of every other (v^T H v partials; norm partials), contiguous
-  int* abort;            // so that a wave reads them as whole cache lines
+  qx_u64* base;          // one buffer: every value that crosses is a 16-byte pair of tagged words, stored and loaded as ONE access
+  unsigned oB, oC;       // [2][256][3T | 3E] values: what a workgroup publishes for its row / column partners (byte offsets)
+  unsigned oBv, oCn;     // [2][256][1 | 2] values: what every workgroup reads of every other (v^T H v partials; norm partials),
+  unsigned bytes;        // contiguous so that a wave reads them as whole cache lines
+  int* abort;
 };
-struct HpReq { const qx_u64* slot; int v; bool on; };
-
-template <int K>
-__device__ __forceinline__ void hp_wait(const HpReq (&r)[K], double (&x)[K], unsigned tag, bool& dead, const HessPx& X, int* status) {
-  bool need[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) need[k] = r[k].on;
-  for (int n = 0; n < QX_SPIN_LIMIT; n++) {
-    bool ok = true;                                      // (only what has not arrived yet is asked for again)
-#pragma unroll
-    for (int k = 0; k < K; k++)
-      if (need[k]) {
-        bool okk = true;
-        const double v = qx_ld(r[k].slot, r[k].v, tag, okk);
-        if (okk) { x[k] = v; need[k] = false; } else ok = false;
-      }
-    if (ok) return;
-    if ((n & 255) == 255 && __hip_atomic_load(X.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; return; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  dead = true;
-  __hip_atomic_store(X.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  qx_raise(status);
-}
-
-// a + b of the partner 16 / 32 lanes away where each keeps one of two values: lanes with the bit clear end with lo(own) + lo(partner),
-// lanes with the bit set with hi(own) + hi(partner) (v_permlane{16,32}_swap exchange the odd rows / upper half of the first operand
-// with the even rows / lower half of the second)
-__device__ __forceinline__ double hp_fold16(double lo, double hi) {
-  const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(lo), __double2loint(hi), false, false);
-  const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(lo), __double2hiint(hi), false, false);
-  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
-}
-__device__ __forceinline__ double hp_fold32(double lo, double hi) {
-  const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(lo), __double2loint(hi), false, false);
-  const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(lo), __double2hiint(hi), false, false);
-  return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
-}
-
 template <int E>
-__global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, double* __restrict__ vrows, HessPx X, int* status, int drop_row, long long* stamps) {
+__global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, double* __restrict__ vrows, HessPx X, int* status, int drop_row, long long* stamps, int delay) {
   using namespace nd4dpp;
   constexpr int T = 16 * E;
-  constexpr int BW = 2 * (3 * T), CW = 2 * (3 * E);
+  constexpr int BV = 3 * T, CV = 3 * E;                              // values per slot
   constexpr int LE = E == 8 ? 3 : (E == 4 ? 2 : 1);                 // log2 E
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, tr = t >> 4, tc = t & 15;
   const int wg = blockIdx.x, p = wg >> 4, q = wg & 15;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X.base, 0, (int)X.bytes, 0x00020000);
   __shared__ double s_rc[T], s_rr[T], s_v[T], s_w[T], s_y[T], s_xp[4][T], s_yp[T], s_q[32 * E], s_e[16 + E];
   __shared__ double s_wm[4], s_wS[4], s_vy[4], s_red[4], s_h0;
   __shared__ int s_dead;
@@ -551,7 +515,8 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
     const unsigned tag = (unsigned)i;
     const int par = i & 1, ii = i - 1;
     const int pi = i / T, pn = ii / T, ln = ii % T;                // row block of row i; row block and local index of row i-1
-    qx_u64* bslot = X.B + ((long)par * 256 + wg) * BW;
+    const unsigned Bp = X.oB + (unsigned)par * 256 * BV * 16, Cp = X.oC + (unsigned)par * 256 * CV * 16;
+    const unsigned bslot = Bp + (unsigned)wg * BV * 16;
     // row i-1 as it stands (before this step's update), by the 16 lanes that hold it
     if (p == pn && tr == (ln & 15) && i != drop_row) {
 #pragma unroll
@@ -559,7 +524,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
         double x = 0.0;
 #pragma unroll
         for (int a = 0; a < E; a++) if (a == (ln >> 4)) x = h[a][b];
-        qx_st(bslot, 2 * T + tc + 16 * b, x, tag);
+        hp_st(rs, bslot + (2 * T + tc + 16 * b) * 16, x, tag);
       }
     }
     // ---- the reflector's scalars (hessenberg.js:43-56), by every thread in the same order
@@ -619,68 +584,28 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
       for (int b = 0; b < E; b++) vy = fma(xs[b], vc[b], vy);
       vy = wave_sum(vy);
       if (lane == 0) s_vy[wave] = vy;
-      // y: over the 16 lanes of a row of lanes; halving exchanges first (each lane ends with the row tc >> (4 - LE)), then plain ones
-      {
-        int n = E;
-        double z[E];
-#pragma unroll
-        for (int a = 0; a < E; a++) z[a] = ys[a];
-        if constexpr (E >= 2) {
-          const bool up = (tc & 8) != 0;
-#pragma unroll
-          for (int k = 0; k < E / 2; k++) { const double keep = up ? z[k + E / 2] : z[k], send = up ? z[k] : z[k + E / 2]; z[k] = keep + xor8(send); }
-          n = E / 2;
-        }
-        if constexpr (E >= 4) {
-          const bool up = (tc & 4) != 0;
-#pragma unroll
-          for (int k = 0; k < E / 4; k++) { const double keep = up ? z[k + E / 4] : z[k], send = up ? z[k] : z[k + E / 4]; z[k] = keep + xor4(send); }
-          n = E / 4;
-        } else z[0] += xor4(z[0]);
-        if constexpr (E >= 8) {
-          const bool up = (tc & 2) != 0;
-          const double keep = up ? z[1] : z[0], send = up ? z[0] : z[1];
-          z[0] = keep + xor2(send);
-        } else z[0] += xor2(z[0]);
-        z[0] += xor1(z[0]);
-        (void)n;
-        if ((tc & ((16 >> LE) - 1)) == 0) s_yp[tr + 16 * (tc >> (4 - LE))] = z[0];
-      }
-      // x: over the 4 lane rows of the wave (then over the waves through LDS)
-      if constexpr (E == 8) {
-        double z[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) z[k] = hp_fold16(xs[k], xs[k + 4]);
-        const double z0 = hp_fold32(z[0], z[2]), z1 = hp_fold32(z[1], z[3]);
-        const int b0 = 4 * (tr & 1) + 2 * ((tr >> 1) & 1);
-        s_xp[wave][tc + 16 * b0] = z0; s_xp[wave][tc + 16 * (b0 + 1)] = z1;
-      } else if constexpr (E == 4) {
-        const double z0 = hp_fold16(xs[0], xs[2]), z1 = hp_fold16(xs[1], xs[3]);
-        const double zz = hp_fold32(z0, z1);
-        s_xp[wave][tc + 16 * (2 * (tr & 1) + ((tr >> 1) & 1))] = zz;
-      } else {
-        const double z0 = hp_fold16(xs[0], xs[1]);
-        const double zz = hp_fold32(z0, z0);
-        if (lane < 32) s_xp[wave][tc + 16 * (tr & 1)] = zz;
-      }
+      // y over the 16 lanes of a lane row (each lane ends with the row tc >> (4 - LE)), x over the 4 lane rows of the wave (then over
+      // the waves through LDS)
+      const double ysum = hp_sum_over_tc<E>(ys, tc);
+      if ((tc & ((16 >> LE) - 1)) == 0) s_yp[tr + 16 * (tc >> (4 - LE))] = ysum;
+      hp_sum_over_tr<E>(xs, tr, tc, lane, s_xp[wave]);
     }
     __syncthreads();
     HP_STAMP(1)
-    if (t < T) qx_st(bslot, t, skip ? 0.0 : (s_xp[0][t] + s_xp[1][t]) + (s_xp[2][t] + s_xp[3][t]), tag);
-    else if (t < 2 * T) qx_st(bslot, t, skip ? 0.0 : s_yp[t - T], tag);
-    if (t == 0) qx_st(X.Bv + (long)par * 512, wg, skip ? 0.0 : (s_vy[0] + s_vy[1]) + (s_vy[2] + s_vy[3]), tag);
+    if (t < T) hp_st(rs, bslot + t * 16, skip ? 0.0 : (s_xp[0][t] + s_xp[1][t]) + (s_xp[2][t] + s_xp[3][t]), tag);
+    else if (t < 2 * T) hp_st(rs, bslot + t * 16, skip ? 0.0 : s_yp[t - T], tag);
+    if (t == 0) hp_st(rs, X.oBv + (par * 256 + wg) * 16, skip ? 0.0 : (s_vy[0] + s_vy[1]) + (s_vy[2] + s_vy[3]), tag);
     // the 16 partials of this workgroup's E columns of x and E rows of y, all 256 partials of v^T y, the 16 partials of y at row
     // i-1 and this workgroup's E columns of row i-1
     {
       HpReq rq[3];
       double xv[3] = {0.0, 0.0, 0.0};
-      const qx_u64* Bp = X.B + (long)par * 256 * BW;
-      if (t < 16 * E) rq[0] = HpReq{Bp + (long)((t / E) * 16 + q) * BW, E * p + t % E, true};
-      else { const int u = t - 16 * E; rq[0] = HpReq{Bp + (long)(p * 16 + u / E) * BW, T + E * q + u % E, t < 32 * E}; }
-      rq[1] = HpReq{X.Bv + (long)par * 512, t, true};
-      if (t < 16) rq[2] = HpReq{Bp + (long)(pn * 16 + t) * BW, T + ln, true};
-      else rq[2] = HpReq{Bp + (long)(pn * 16 + q) * BW, 2 * T + E * p + (t - 16), t < 16 + E};
-      hp_wait<3>(rq, xv, tag, dead, X, status);
+      if (t < 16 * E) rq[0] = HpReq{Bp + (unsigned)(((t / E) * 16 + q) * BV + E * p + t % E) * 16, true};
+      else { const int u = t - 16 * E; rq[0] = HpReq{Bp + (unsigned)((p * 16 + u / E) * BV + T + E * q + u % E) * 16, t < 32 * E}; }
+      rq[1] = HpReq{X.oBv + (unsigned)(par * 256 + t) * 16, true};
+      if (t < 16) rq[2] = HpReq{Bp + (unsigned)((pn * 16 + t) * BV + T + ln) * 16, true};
+      else rq[2] = HpReq{Bp + (unsigned)((pn * 16 + q) * BV + 2 * T + E * p + (t - 16)) * 16, t < 16 + E};
+      hp_wait<3>(rs, rq, xv, tag, dead, X.abort, status, delay);
       if (t < 32 * E) s_q[t] = xv[0];
       if (t < 16 + E) s_e[t] = xv[2];
       const double vys = wave_sum(xv[1]);
@@ -695,7 +620,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
       double s = 0.0;
 #pragma unroll
       for (int pp = 0; pp < 16; pp++) s += s_q[(t < E ? 0 : 16 * E) + pp * E + c];
-      qx_u64* cslot = X.C + ((long)par * 256 + wg) * CW;
+      const unsigned cslot = Cp + (unsigned)wg * CV * 16;
       if (t < E) {
         const double vy = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         const double ve = s_v[E * p + c];
@@ -714,30 +639,29 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
         if constexpr (E >= 2) ss += xor1(ss);
         if constexpr (E >= 4) ss += xor2(ss);
         if constexpr (E >= 8) ss += xor4(ss);
-        qx_st(cslot, c, w, tag);
-        qx_st(cslot, 2 * E + c, rn, tag);
-        if (c == 0) { qx_st(X.Cn + (long)par * 1024, 2 * wg, m, tag); qx_st(X.Cn + (long)par * 1024, 2 * wg + 1, ss, tag); }
+        hp_st(rs, cslot + c * 16, w, tag);
+        hp_st(rs, cslot + (2 * E + c) * 16, rn, tag);
+        if (c == 0) { hp_st(rs, X.oCn + (par * 512 + 2 * wg) * 16, m, tag); hp_st(rs, X.oCn + (par * 512 + 2 * wg + 1) * 16, ss, tag); }
       } else {
-        qx_st(cslot, E + c, (T * p + E * q + c < i) ? s : 0.0, tag);      // y, rows < i only
+        hp_st(rs, cslot + (E + c) * 16, (T * p + E * q + c < i) ? s : 0.0, tag);      // y, rows < i only
       }
     }
     // ---- C: w over the columns q, y over the rows p, the next row over both, the norm partials, the entry (i-1, i-2)
     {
       HpReq rq[5];
       double xv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-      const qx_u64* Cp = X.C + (long)par * 256 * CW;
       if (t < T) {
-        const qx_u64* s = Cp + (long)((t / E) * 16 + q) * CW;
-        rq[0] = HpReq{s, t % E, true}; rq[1] = HpReq{s, 2 * E + t % E, true};
+        const unsigned s = Cp + (unsigned)(((t / E) * 16 + q) * CV) * 16;
+        rq[0] = HpReq{s + (t % E) * 16, true}; rq[1] = HpReq{s + (2 * E + t % E) * 16, true};
       } else {
         const int j = t - T;
-        rq[0] = HpReq{Cp + (long)(p * 16 + j / E) * CW, E + j % E, t < 2 * T};
-        rq[1] = HpReq{Cp + (long)((j / E) * 16 + p) * CW, 2 * E + j % E, t < 2 * T};
+        rq[0] = HpReq{Cp + (unsigned)((p * 16 + j / E) * CV + E + j % E) * 16, t < 2 * T};
+        rq[1] = HpReq{Cp + (unsigned)(((j / E) * 16 + p) * CV + 2 * E + j % E) * 16, t < 2 * T};
       }
-      rq[2] = HpReq{X.Cn + (long)par * 1024, 2 * t, true};
-      rq[3] = HpReq{X.Cn + (long)par * 1024, 2 * t + 1, true};
-      { const int e = ii - 1 < 0 ? 0 : ii - 1, j = e % T; rq[4] = HpReq{Cp + (long)((j / E) * 16 + e / T) * CW, 2 * E + j % E, t == 0}; }
-      hp_wait<5>(rq, xv, tag, dead, X, status);
+      rq[2] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t) * 16, true};
+      rq[3] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t + 1) * 16, true};
+      { const int e = ii - 1 < 0 ? 0 : ii - 1, j = e % T; rq[4] = HpReq{Cp + (unsigned)(((j / E) * 16 + e / T) * CV + 2 * E + j % E) * 16, t == 0}; }
+      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay);
       if (t < T) { s_w[t] = xv[0]; s_rc[t] = xv[1]; }
       else if (t < 2 * T) { s_y[t - T] = xv[0]; s_rr[t - T] = xv[1]; }
       if (t == 0) s_h0 = xv[4];
@@ -821,23 +745,25 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
   if (persist) {
     // ---- one launch: 16 x 16 workgroups keep H in registers for the whole reduction (see hessp) ----
     const int E = N <= 512 ? 2 : (N <= 1024 ? 4 : 8), T = 16 * E;
-    const size_t BW = 2 * (3 * T), CW = 2 * (3 * E);
-    const size_t xwords = 2 * 256 * (BW + CW) + 2 * 512 + 2 * 1024;
+    const size_t BV = 3 * T, CV = 3 * E;                                                    // values (16 bytes each) per slot
+    const size_t xwords = 2 * (2 * 256 * (BV + CV) + 2 * 256 + 2 * 512);
     void* q = nullptr;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, &q));
     double* vrows = static_cast<double*>(q);
     HessPx X;
-    X.B = reinterpret_cast<qx_u64*>(vrows + (size_t)nstore * N); X.C = X.B + 2 * 256 * BW;
-    X.Bv = X.C + 2 * 256 * CW; X.Cn = X.Bv + 2 * 512;
-    X.abort = reinterpret_cast<int*>(X.Cn + 2 * 1024);
+    X.base = reinterpret_cast<qx_u64*>(vrows + (size_t)nstore * N);
+    X.oB = 0; X.oC = (unsigned)(2 * 256 * BV * 16); X.oBv = X.oC + (unsigned)(2 * 256 * CV * 16); X.oCn = X.oBv + 2 * 256 * 16;
+    X.bytes = X.oCn + 2 * 512 * 16;
+    X.abort = reinterpret_cast<int*>(X.base + xwords);
     ND4_HIP(hipMemsetAsync(vrows, 0, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, h->stream));
     const int drop = nd4_test_drop_panel() >= 0 ? N - 1 - nd4_test_drop_panel() : -1;       // test hook: row N-1-k is never published
     static const bool want_stamps = getenv("ND4HIP_HESSP_STAMPS") != nullptr;
+    const int delay = getenv("ND4HIP_HESSP_DELAY") ? atoi(getenv("ND4HIP_HESSP_DELAY")) : 4;     // s_sleep(8) units before the first look of a round
     long long* stamps = nullptr;
     if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
-    if (E == 2) hipLaunchKernelGGL(hessp<2>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
-    else if (E == 4) hipLaunchKernelGGL(hessp<4>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
-    else hipLaunchKernelGGL(hessp<8>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps);
+    if (E == 2) hipLaunchKernelGGL(hessp<2>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps, delay);
+    else if (E == 4) hipLaunchKernelGGL(hessp<4>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps, delay);
+    else hipLaunchKernelGGL(hessp<8>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps, delay);
     ND4_HIP(hipGetLastError());
     if (stamps) {                                     // per step, in us: reflector | products | B | sums + C | update
       long long hs[256 * 8];
