@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       double xv[2] = {0.0, 0.0};
       rq[0] = HpReq{R1p + (unsigned)((((t / E) & 15) * 16 + q) * V1 + E * p + t % E) * 16, t < 16 * E};
       rq[1] = HpReq{R1p + (unsigned)((pi * 16 + q) * V1 + T + E * p + (t % E)) * 16, t < E};
-      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay >> 8);
       if (t < 16 * E) s_q[t] = xv[0];
       if (t < E) s_q[16 * E + t] = xv[1];
     }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       const unsigned srcf = R2p + (unsigned)(((jf / E) * 16 + ef / T) * V2) * 16;
       rq[5] = HpReq{srcf + (E + jf % E) * 16, t == 0};
       rq[6] = HpReq{srcf + (jf % E) * 16, t == 0};
-      hp_wait<7>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<7>(rs, rq, xv, tag, dead, X.abort, status, delay & 255);
       if (t < T) { s_z[t] = xv[0]; s_r[t] = xv[1]; }
       if (t == 0) { s_x0 = xv[5]; s_z0 = xv[6]; }
       const double wm = wave_max(xv[2]);
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       double xv[2] = {0.0, 0.0};
       rq[0] = HpReq{R3p + (unsigned)((p * 16 + ((t / E) & 15)) * V3 + E * q + t % E) * 16, t < 16 * E};
       rq[1] = HpReq{R1p + (unsigned)((p * 16 + q1) * V1 + 2 * T + E * q + (t % E)) * 16, t < E};
-      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<2>(rs, rq, xv, tag, dead, X.abort, status, delay >> 8);
       if (t < 16 * E) s_q[t] = xv[0];
       if (t < E) s_q[16 * E + t] = xv[1];
     }
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       rq[2] = HpReq{A4p + (unsigned)(t * 2) * 16, true};
       rq[3] = HpReq{A4p + (unsigned)(t * 2 + 1) * 16, true};
       rq[4] = HpReq{R4p + (unsigned)((q1 * 16 + l1 / E) * V4 + E + l1 % E) * 16, t == 0};       // row i+1: block q1, local l1
-      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay & 255);
       if (t < T) { s_y[t] = xv[0]; s_cu[t] = xv[1]; }
       if (t == 0) s_alpha = xv[4];
       const double wm = wave_max(xv[2]);
@@ -826,7 +826,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
 
   // ---- factorisation ----
   static const bool fused_off = getenv("ND4HIP_BIDIAG_UNFUSED") != nullptr;          // A/B switch
-  static const bool no_persist = getenv("ND4HIP_BIDIAG_NO_PERSIST") != nullptr;
+  const bool no_persist = getenv("ND4HIP_BIDIAG_NO_PERSIST") != nullptr;          // (read per call: the tests switch between the paths)
   if (!fused_off && !no_persist && batch == 1 && M >= 128 && N >= 128 && M <= 2048 && N <= 2048) {
     // ---- one launch: 16 x 16 workgroups keep the matrix in registers for the whole reduction (see bdp) ----
     const int E = mx <= 512 ? 2 : (mx <= 1024 ? 4 : 8), T = 16 * E;
@@ -843,7 +843,8 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     X.abort = reinterpret_cast<int*>(reinterpret_cast<char*>(X.base) + xbytes);
     ND4_HIP(hipMemsetAsync(X.base, 0, xbytes + 64, h->stream));
     static const bool want_stamps = getenv("ND4HIP_BDP_STAMPS") != nullptr;
-    const int delay = getenv("ND4HIP_BDP_DELAY") ? atoi(getenv("ND4HIP_BDP_DELAY")) : 4;         // s_sleep(8) units before the first look of a round
+    // s_sleep(8) units (~0.22 us) before the first look of rounds 1 / 3 (high byte) and rounds 2 / 4 (low byte)
+    const int delay = getenv("ND4HIP_BDP_DELAY") ? atoi(getenv("ND4HIP_BDP_DELAY")) : (0 << 8 | 4);
     long long* stamps = nullptr;
     if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
     if (E == 2) hipLaunchKernelGGL(bdp<2>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
       rq[1] = HpReq{X.oBv + (unsigned)(par * 256 + t) * 16, true};
       if (t < 16) rq[2] = HpReq{Bp + (unsigned)((pn * 16 + t) * BV + T + ln) * 16, true};
       else rq[2] = HpReq{Bp + (unsigned)((pn * 16 + q) * BV + 2 * T + E * p + (t - 16)) * 16, t < 16 + E};
-      hp_wait<3>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<3>(rs, rq, xv, tag, dead, X.abort, status, delay >> 8);
       if (t < 32 * E) s_q[t] = xv[0];
       if (t < 16 + E) s_e[t] = xv[2];
       const double vys = wave_sum(xv[1]);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
       rq[2] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t) * 16, true};
       rq[3] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t + 1) * 16, true};
       { const int e = ii - 1 < 0 ? 0 : ii - 1, j = e % T; rq[4] = HpReq{Cp + (unsigned)(((j / E) * 16 + e / T) * CV + 2 * E + j % E) * 16, t == 0}; }
-      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay);
+      hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay & 255);
       if (t < T) { s_w[t] = xv[0]; s_rc[t] = xv[1]; }
       else if (t < 2 * T) { s_y[t - T] = xv[0]; s_rr[t - T] = xv[1]; }
       if (t == 0) s_h0 = xv[4];
@@ -740,7 +740,7 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
   }
   const int cchunks = (N + 255) / 256;
   const bool blocked_path = wy && batch == 1 && N >= 512 && (N & 1) == 0 && (size_t)N * sizeof(double) <= 48 * 1024 && !getenv("ND4HIP_HESS_UNBLOCKED");
-  static const bool no_persist = getenv("ND4HIP_HESS_NO_PERSIST") != nullptr;
+  const bool no_persist = getenv("ND4HIP_HESS_NO_PERSIST") != nullptr;            // (read per call: the tests switch between the paths)
   const bool persist = wy && batch == 1 && N >= 128 && N <= 2048 && !no_persist && !getenv("ND4HIP_HESS_UNBLOCKED");
   if (persist) {
     // ---- one launch: 16 x 16 workgroups keep H in registers for the whole reduction (see hessp) ----
@@ -758,7 +758,8 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
     ND4_HIP(hipMemsetAsync(vrows, 0, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, h->stream));
     const int drop = nd4_test_drop_panel() >= 0 ? N - 1 - nd4_test_drop_panel() : -1;       // test hook: row N-1-k is never published
     static const bool want_stamps = getenv("ND4HIP_HESSP_STAMPS") != nullptr;
-    const int delay = getenv("ND4HIP_HESSP_DELAY") ? atoi(getenv("ND4HIP_HESSP_DELAY")) : 4;     // s_sleep(8) units before the first look of a round
+    // s_sleep(8) units (~0.22 us) before the first look of round B (high byte) and round C (low byte)
+    const int delay = getenv("ND4HIP_HESSP_DELAY") ? atoi(getenv("ND4HIP_HESSP_DELAY")) : (2 << 8 | 4);
     long long* stamps = nullptr;
     if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
     if (E == 2) hipLaunchKernelGGL(hessp<2>, dim3(256), dim3(256), 0, h->stream, H, N, vrows, X, h->xstat, drop, stamps, delay);

@@ -100,3 +100,27 @@ def test_fused_path_large(la, M, N):
         tol = 256 * EPS * n
         assert np.abs(b - bo).max() <= tol * np.abs(a).max() * n ** 0.5
         assert np.abs(u - uo).max() <= tol * 8 and np.abs(v - vo).max() <= tol * 8
+
+
+@pytest.mark.parametrize("M,N", [(2048, 130), (130, 2048), (1025, 1023), (1023, 1025), (2047, 2047), (513, 512)])
+def test_one_launch_reduction_shapes(la, M, N):
+    """one matrix with 128 <= M, N <= 2048 is reduced by ONE launch (bidiag.hip: bdp) — 16 x 16 workgroups hold the
+    matrix as tiles in registers, four rounds of tagged words per step. Shapes far from square (most tiles empty), odd extents, both
+    M > N and M < N: the reference's properties (bidiag_test.js), and the singular values against LAPACK's."""
+    a = rng.matrix(7600 + M + N, M, N)
+    u, b, v = la.bidiag_decomp(a)
+    check_props(a, u, b, v)
+    sv = np.linalg.svd(b, compute_uv=False)
+    assert np.abs(sv - np.linalg.svd(a, compute_uv=False)[: len(sv)]).max() <= 1e-11 * np.abs(a).max() * max(M, N)
+
+
+@pytest.mark.parametrize("M,N", [(512, 512), (300, 299), (257, 129)])
+def test_fused_path_below_the_one_launch_cap(la, M, N, monkeypatch):
+    """The fused two-launch path (what shapes beyond 2048 take) on shapes the one-launch reduction would take: same checks."""
+    monkeypatch.setenv("ND4HIP_BIDIAG_NO_PERSIST", "1")
+    a = rng.matrix(7700 + M + N, M, N)
+    u, b, v = la.bidiag_decomp(a)
+    check_props(a, u, b, v)
+    if M * N <= 300 * 300:
+        uo, bo, vo = oracle.bidiag_decomp(a)
+        assert np.abs(b - bo).max() <= 1e-11 * max(M, N) and np.abs(u - uo).max() <= 1e-10 and np.abs(v - vo).max() <= 1e-10

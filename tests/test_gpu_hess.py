@@ -71,9 +71,11 @@ def test_hessenberg_batch_and_device(la):
 
 
 @pytest.mark.parametrize("N", [512, 600])
-def test_blocked_path_vs_oracle(la, N):
-    """N >= 512 (one matrix, even N) takes the blocked two-launch step (hess.hip: hessb_pass / hessb_reduce): values against the
-    oracle, which is bit-identical to the reference on the goldens."""
+def test_blocked_path_vs_oracle(la, N, monkeypatch):
+    """One matrix with even N >= 512 beyond the one-launch reduction (N > 2048, or ND4HIP_HESS_NO_PERSIST as here) takes the blocked
+    two-launch step (hess.hip: hessb_pass / hessb_reduce): values against the oracle, which is bit-identical to the reference on the
+    goldens."""
+    monkeypatch.setenv("ND4HIP_HESS_NO_PERSIST", "1")
     a = rng.matrix(6400 + N, N, N)
     u, h = la.hessenberg_decomp(a)
     check_props(a, u, h)
@@ -83,9 +85,13 @@ def test_blocked_path_vs_oracle(la, N):
     assert np.abs(u - uo).max() <= 64 * eps * N
 
 
-def test_blocked_path_skipped_steps(la):
+@pytest.mark.parametrize("persist", [True, False])
+def test_blocked_path_skipped_steps(la, persist, monkeypatch):
     """Rows that are already in Hessenberg form are skipped (hessenberg.js:46): all of them (the input comes back bit-identical, U = I),
-    and a mix of skipped and reflected steps inside one block of 32."""
+    and a mix of skipped and reflected steps inside one block of 32 — in the one-launch reduction (a skipped step still runs its two
+    exchange rounds) and in the blocked path."""
+    if not persist:
+        monkeypatch.setenv("ND4HIP_HESS_NO_PERSIST", "1")
     N = 512
     hess = np.triu(rng.matrix(6500, N, N), -1)
     u, h = la.hessenberg_decomp(hess)
@@ -116,3 +122,25 @@ def test_blocked_path_large(la, N):
         uo, ho = oracle.hessenberg_decomp(a)
         assert np.abs(h - ho).max() <= 64 * EPS * N * np.abs(a).max() * N ** 0.5
         assert np.abs(u - uo).max() <= 64 * EPS * N
+
+
+@pytest.mark.parametrize("N", [128, 129, 255, 513, 1025, 2047])
+def test_one_launch_reduction_sizes(la, N):
+    """128 <= N <= 2048 (one matrix) is reduced by ONE launch (hess.hip: hessp) — 16 x 16 workgroups hold H as tiles
+    in registers, two rounds of tagged words per step. Sizes that do not fill the tiles (zero padding), odd N, the three tile edges
+    (32, 64, 128): properties of hessenberg_test.js, and the values against the oracle where it is quick."""
+    a = rng.matrix(6700 + N, N, N)
+    u, h = la.hessenberg_decomp(a)
+    check_props(a, u, h)
+    if N <= 513:
+        uo, ho = oracle.hessenberg_decomp(a)
+        assert np.abs(h - ho).max() <= 64 * EPS * N * np.abs(a).max() * N ** 0.5
+        assert np.abs(u - uo).max() <= 64 * EPS * N
+
+
+def test_blocked_path_beyond_the_one_launch_reduction(la):
+    """N > 2048 no longer fits the registers of 256 workgroups: the blocked path, by its properties."""
+    N = 2304
+    a = rng.matrix(6800, N, N)
+    u, h = la.hessenberg_decomp(a)
+    check_props(a, u, h)
