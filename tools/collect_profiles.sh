@@ -28,6 +28,8 @@ pmc qrlu2048_fetch FETCH_SIZE python3 $R/tools/prof_ops.py qr lu --reps 1
 pmc qrlu2048_write WRITE_SIZE python3 $R/tools/prof_ops.py qr lu --reps 1
 pmc small_fetch FETCH_SIZE python3 $R/tools/prof_small.py
 pmc small_write WRITE_SIZE python3 $R/tools/prof_small.py
+pmc hess_fetch FETCH_SIZE python3 $R/tools/prof_hess.py 2048 hess bidiag
+pmc hess_write WRITE_SIZE python3 $R/tools/prof_hess.py 2048 hess bidiag
 pmc svd_fetch FETCH_SIZE python3 $R/tools/prof_ops.py svd --reps 1
 pmc svd_write WRITE_SIZE python3 $R/tools/prof_ops.py svd --reps 1
 # summaries (tools/pmc_summary.py: FETCH_SIZE x2 + WRITE_SIZE, KB -> bytes)
@@ -36,11 +38,13 @@ S $out/gemm4096_pmc.json dgemm_kernel $out/gemm_fetch/p_counter_collection.csv $
 S $out/qr_panel_batched_pmc.json "qrb_panel<4, 8;qrb_panel<4, 2" $out/panel_fetch/p_counter_collection.csv $out/panel_write/p_counter_collection.csv
 S $out/qr_lu_2048_pmc.json "qrh_bc<4,qrh_bc<2,qrh_bc<1,lu_panel_row_la<4,lu_panel_row_la<2,lu_panel_row_la<1,lu_narrow_fused" $out/qrlu2048_fetch/p_counter_collection.csv $out/qrlu2048_write/p_counter_collection.csv
 S $out/svd_small_pmc.json "jac_small<32" $out/small_fetch/p_counter_collection.csv $out/small_write/p_counter_collection.csv
+S $out/hess_bidiag_2048_pmc.json "hessp<8;bdp<8" $out/hess_fetch/p_counter_collection.csv $out/hess_write/p_counter_collection.csv
 S $out/svd2048_pmc.json "jacb_eigen_pu,jacb_apply_w,jacb_gram2" $out/svd_fetch/p_counter_collection.csv $out/svd_write/p_counter_collection.csv
 # the in-kernel phase stamps: the batched QR panel (workgroup 0), the one-launch QR panels of one matrix; the ceilings of the panel's
 # data movement (copy-only modes) and of a plain device copy
 ND4HIP_QRB_STAMPS=1 python3 $R/tools/panel_stamps.py 2>&1 | grep 'qrb stamps' > $out/qr_panel_batched_phase_stamps.txt
 ND4HIP_QR_STAMPS=1 python3 $R/tools/prof_ops.py qr --n 2048 --reps 1 2>&1 | grep 'qrh stamp' > $out/qr2048_panel_phase_stamps.txt
+ND4HIP_HESSP_STAMPS=1 ND4HIP_BDP_STAMPS=1 python3 $R/tools/time_hess.py 2048 2>&1 | grep -E '^hessp|^bdp' | sort -u > $out/hess_bidiag_phase_stamps.txt
 ( echo "== thread-per-row copy (ND4HIP_QRB_COPY_ONLY=1)"; ND4HIP_QRB_COPY_ONLY=1 python3 $R/tools/time_panel.py 2>/dev/null; echo "== whole-line copy (=2)"; ND4HIP_QRB_COPY_ONLY=2 python3 $R/tools/time_panel.py 2>/dev/null; echo "== plain device copy"; python3 $R/tools/copy_bw.py ) > $out/qr_panel_copy_ceiling.txt 2>&1
 python3 $R/tools/time_batch.py 1024 lu qr > $out/lu_qr_batch_times.txt 2>&1
 python3 $R/bench.py > $out/bench_default.json 2> $out/bench_default.err
