@@ -827,7 +827,15 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
   // ---- factorisation ----
   static const bool fused_off = getenv("ND4HIP_BIDIAG_UNFUSED") != nullptr;          // A/B switch
   const bool no_persist = getenv("ND4HIP_BIDIAG_NO_PERSIST") != nullptr;          // (read per call: the tests switch between the paths)
-  if (!fused_off && !no_persist && batch == 1 && M >= 128 && N >= 128 && M <= 2048 && N <= 2048) {
+  bool persist = !fused_off && !no_persist && batch == 1 && M >= 128 && N >= 128 && M <= 2048 && N <= 2048;
+  if (persist) {                                             // (the 256 workgroups of bdp must all be resident at once, see xchg.h)
+    int per_cu = 0;
+    const hipError_t oe = mx <= 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bdp<2>, 256, 0)
+                        : mx <= 1024 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bdp<4>, 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bdp<8>, 256, 0);
+    persist = oe == hipSuccess && (long)per_cu * h->num_cu >= 256;
+  }
+  if (persist) {
     // ---- one launch: 16 x 16 workgroups keep the matrix in registers for the whole reduction (see bdp) ----
     const int E = mx <= 512 ? 2 : (mx <= 1024 ? 4 : 8), T = 16 * E;
     const size_t V1 = 3 * T, V2 = 2 * E, V3 = T, V4 = 2 * E;

@@ -741,7 +741,15 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
   const int cchunks = (N + 255) / 256;
   const bool blocked_path = wy && batch == 1 && N >= 512 && (N & 1) == 0 && (size_t)N * sizeof(double) <= 48 * 1024 && !getenv("ND4HIP_HESS_UNBLOCKED");
   const bool no_persist = getenv("ND4HIP_HESS_NO_PERSIST") != nullptr;            // (read per call: the tests switch between the paths)
-  const bool persist = wy && batch == 1 && N >= 128 && N <= 2048 && !no_persist && !getenv("ND4HIP_HESS_UNBLOCKED");
+  // (the 256 workgroups of hessp must all be resident at once: one or two per CU, see xchg.h)
+  bool persist = wy && batch == 1 && N >= 128 && N <= 2048 && !no_persist && !getenv("ND4HIP_HESS_UNBLOCKED");
+  if (persist) {
+    int per_cu = 0;
+    const hipError_t oe = N <= 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hessp<2>, 256, 0)
+                        : N <= 1024 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hessp<4>, 256, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hessp<8>, 256, 0);
+    persist = oe == hipSuccess && (long)per_cu * h->num_cu >= 256;
+  }
   if (persist) {
     // ---- one launch: 16 x 16 workgroups keep H in registers for the whole reduction (see hessp) ----
     const int E = N <= 512 ? 2 : (N <= 1024 ? 4 : 8), T = 16 * E;

@@ -2472,6 +2472,63 @@ struct QrhHost {
 
 }  // namespace
 
+// Compact-WY factor of up to 64 reflector columns = up to four panels of a batch member: T (n x n) from the panels' 16 x 16 factors
+// on its diagonal and G = V^T V, T12 = -T1 (V1^T V2) T2 level by level (16, then 32 columns; valid for the FULL factors of the
+// matrix-core panels as well as for triangular ones). One workgroup per matrix, everything in LDS: each G12 block is used once, so
+// G12 T2 overwrites it. Batches beyond the look-ahead form (qr_batch: the rank-16 updates were 56 % of the run).
+__global__ __launch_bounds__(256) void wy_t_small(const double* __restrict__ Tdiag, long sTd, const double* __restrict__ G, int ldg, long sG,
+                                                   double* __restrict__ Tout, int ldt, long sTo, int n) {
+  __shared__ double s_t[64 * 64], s_g[64 * 64];
+  const long m = blockIdx.x;
+  const int t = threadIdx.x;
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    const bool in = i < n && j < n;
+    s_g[e] = in ? G[m * sG + (long)i * ldg + j] : 0.0;
+    s_t[e] = (in && (i >> 4) == (j >> 4)) ? Tdiag[m * sTd + (long)(i >> 4) * 256 + (i & 15) * 16 + (j & 15)] : 0.0;
+  }
+  __syncthreads();
+  for (int b = 16; b < n; b <<= 1) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                    // X = G12 T2 on the 12-blocks of this level
+      const int e = t + 256 * k, i = e >> 6, j = e & 63, p0 = i & ~(2 * b - 1);
+      const int qe = (p0 + 2 * b < n) ? p0 + 2 * b : n;
+      double x = 0.0;
+      if (i - p0 < b && j >= p0 + b && j < qe) for (int q = p0 + b; q < qe; q++) x += s_g[i * 64 + q] * s_t[q * 64 + j];
+      v[k] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int e = t + 256 * k, i = e >> 6, j = e & 63, p0 = i & ~(2 * b - 1);
+      const int qe = (p0 + 2 * b < n) ? p0 + 2 * b : n;
+      if (i - p0 < b && j >= p0 + b && j < qe) s_g[e] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                    // T12 = -T1 X
+      const int e = t + 256 * k, i = e >> 6, j = e & 63, p0 = i & ~(2 * b - 1);
+      const int qe = (p0 + 2 * b < n) ? p0 + 2 * b : n;
+      double y = 0.0;
+      if (i - p0 < b && j >= p0 + b && j < qe) for (int q = p0; q < p0 + b; q++) y += s_t[i * 64 + q] * s_g[q * 64 + j];
+      v[k] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int e = t + 256 * k, i = e >> 6, j = e & 63, p0 = i & ~(2 * b - 1);
+      const int qe = (p0 + 2 * b < n) ? p0 + 2 * b : n;
+      if (i - p0 < b && j >= p0 + b && j < qe) s_t[e] = -v[k];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < 4096; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    if (i < n && j < n) Tout[m * sTo + (long)i * ldt + j] = s_t[e];
+  }
+}
+
 static int wy_build_T(nd4hip_handle* h, int M, int n, const double* V, long ldv, const double* Tdiag, int bs, double* Tall, double* G, double* tmp);
 
 int nd4_geqrf_q(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* Q, double* R) {
@@ -2619,6 +2676,8 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     P.stamps = nullptr; P.stamp_slot = 0; P.status = h->xstat; { const int dp = nd4_test_drop_panel(); P.drop_tag = dp >= 0 ? dp + 1 : -1; }
     if (want_stamps) { ND4_HIP(hipMalloc(&P.stamps, sizeof(long long) * 8 * 3 * (npanels + 1))); ND4_HIP(hipMemset(P.stamps, 0, sizeof(long long) * 8 * 3 * (npanels + 1))); }
   }
+  double *btT = nullptr, *btG = nullptr, *btX = nullptr, *btW = nullptr;              // batched two-level form (generic branch below)
+  int bt_ppb = 0; long bt_sT = 0, bt_sX = 0;
   if (lookahead) {
     int pj0 = -1;                                            // first row/column of the previous panel
     const int nq = QT ? (M + NB - 1) / NB : 0;
@@ -2768,8 +2827,23 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
   // T12 = -T1 (V1^T V2) T2 level by level from ONE Gram matrix, the routine Q is formed with) takes all 128 reflectors to the rest at
   // once on the tiled MFMA kernel: X = V^T C, W = T^T X, C -= V W (K = 128). M <= 2048 without look-ahead: one level.
   static const int nbo_env = [] { const char* e = getenv("ND4HIP_QR_OUTER"); return e ? atoi(e) : 128; }();
-  const int ppb = (M > 2048 && nbo_env >= 32) ? nbo_env / NB : npanels;        // panels per outer block
+  // Batches beyond the look-ahead form (M <= 2048), round 4: the same two levels with outer blocks of 128 columns (64 below 256 columns; ND4HIP_QR_BATCH_OUTER:
+  // 32 | 48 | 64 | 128, 0 = off), everything batched — G = Vb^T Vb and the three products of the far update as strided GEMMs over the batch,
+  // the block's T by one small workgroup per matrix (wy_t_small) — and Q formed backwards block by block from the stored T's: the
+  // rank-16 updates of every panel over the whole trailing matrix (56 % of 1024 x 512^2) become rank-128 updates, an eighth of the traffic.
+  static const int qbo_set = [] { const char* e = getenv("ND4HIP_QR_BATCH_OUTER"); return e ? atoi(e) : -1; }();
+  const int qbo_env = qbo_set >= 0 ? qbo_set : (npanels >= 16 ? 128 : 64);          // 1024 x 512^2: 43.8 (off) -> 30.5 (64) -> 23.6 ms (128)
+  const bool batch2 = M <= 2048 && batch > 1 && (qbo_env == 32 || qbo_env == 48 || qbo_env == 64 || qbo_env == 128) && L % NB == 0 && npanels >= 2 * (qbo_env / NB);
+  const int ppb = (M > 2048 && nbo_env >= 32) ? nbo_env / NB : (batch2 ? qbo_env / NB : npanels);        // panels per outer block
   double *farT = nullptr, *farG = nullptr, *farTmp = nullptr, *farX = nullptr, *farW = nullptr;
+  if (batch2) {
+    const size_t nbo = (size_t)ppb * NB, nblocks = (size_t)(npanels + ppb - 1) / ppb, wcols = (size_t)(N > Lq ? N : Lq);
+    void* q = nullptr;
+    ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)batch * (nblocks * nbo * nbo + nbo * nbo + 2 * nbo * wcols) + 64, &q));
+    btT = static_cast<double*>(q); btG = btT + (size_t)batch * nblocks * nbo * nbo; btX = btG + (size_t)batch * nbo * nbo; btW = btX + (size_t)batch * nbo * wcols;
+    bt_ppb = ppb; bt_sT = (long)(nblocks * nbo * nbo); bt_sX = (long)(nbo * wcols);
+    ND4_HIP(hipMemsetAsync(btT, 0, sizeof(double) * (size_t)batch * nblocks * nbo * nbo, h->stream));   // (the blocks below the diagonal 64 x 64 blocks stay zero)
+  } else
   if (ppb < npanels) {
     const size_t nbo = (size_t)ppb * NB;
     void* q = nullptr;
@@ -2816,6 +2890,31 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     // trailing columns of the outer block: C <- H^T C = (I - V T^T V^T) C
     ND4_TRY(apply_block_reflector(h, ws, batch, M, j0, pnl, /*trans=*/1, W + (long)j0 * ld + j0 + nb, ld, sW, bend - j0 - nb));
   }
+  if (batch2) {                                                                    // the block's T for every member; its reflectors on everything right of it
+    const int J = P0 * NB, nblk = (pend - P0) * NB, mJ = M - J, far = N - bend;
+    const long nbo2 = (long)bt_ppb * NB * bt_ppb * NB;
+    const double* Vb = ws.V + (long)J * ws.ldv + J;
+    double* Tb = btT + (long)(P0 / bt_ppb) * nbo2;
+    ND4_TRY(nd4_gemm(h, true, false, nblk, nblk, mJ, 1.0, Vb, ws.ldv, ws.sV, Vb, ws.ldv, ws.sV, 0.0, btG, nblk, nbo2, batch));
+    {
+      // T of the block: 64-column halves in LDS (wy_t_small), the coupling of the two halves of a 128-column block by two products
+      const int n1 = nblk < 64 ? nblk : 64, n2 = nblk - n1;
+      hipLaunchKernelGGL(wy_t_small, dim3((unsigned)batch), dim3(256), 0, h->stream, ws.T + (long)P0 * NB * NB, ws.sT, btG, nblk, nbo2, Tb, nblk, bt_sT, n1);
+      if (n2 > 0) {
+        hipLaunchKernelGGL(wy_t_small, dim3((unsigned)batch), dim3(256), 0, h->stream, ws.T + (long)(P0 + 4) * NB * NB, ws.sT, btG + (long)n1 * nblk + n1, nblk, nbo2,
+                           Tb + (long)n1 * nblk + n1, nblk, bt_sT, n2);
+        ND4_TRY(nd4_gemm(h, false, false, n1, n2, n2, 1.0, btG + n1, nblk, nbo2, Tb + (long)n1 * nblk + n1, nblk, bt_sT, 0.0, btX, n2, bt_sX, batch));
+        ND4_TRY(nd4_gemm(h, false, false, n1, n2, n1, -1.0, Tb, nblk, bt_sT, btX, n2, bt_sX, 0.0, Tb + n1, nblk, bt_sT, batch));
+      }
+      ND4_HIP(hipGetLastError());
+    }
+    if (far > 0) {
+      double* C = W + (long)J * ld + bend;
+      ND4_TRY(nd4_gemm(h, true, false, nblk, far, mJ, 1.0, Vb, ws.ldv, ws.sV, C, ld, sW, 0.0, btX, far, bt_sX, batch));
+      ND4_TRY(nd4_gemm(h, true, false, nblk, far, nblk, 1.0, Tb, nblk, bt_sT, btX, far, bt_sX, 0.0, btW, far, bt_sX, batch));
+      ND4_TRY(nd4_gemm(h, false, false, mJ, far, nblk, -1.0, Vb, ws.ldv, ws.sV, btW, far, bt_sX, 1.0, C, ld, sW, batch));
+    }
+  } else
   if (bend < N) {                                                                  // the block's 128 reflectors on everything right of it
     const int J = P0 * NB, nblk = (pend - P0) * NB, mJ = M - J, far = N - bend;
     for (int mt = 0; mt < batch; mt++) {
@@ -2848,6 +2947,21 @@ int nd4_geqrf_q_ex(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, 
     ND4_TRY(nd4_transpose(h, Lq, M, QT, M, Q, Lq, batch, sQT, sQ));        // Q = (first Lq rows of Q^T)^T
   } else if (!wy_off && batch <= 4 && L >= 256) {
     ND4_TRY(form_q_compact_wy(h, ws, batch, M, Lq, npanels, Q, sQ));
+  } else if (btT != nullptr) {
+    // batches, two-level: Q <- (I - Vb Tb Vb^T) Q block by block, backwards, with the blocks' stored factors
+    ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, batch, sQ));
+    const long nbo2 = (long)bt_ppb * NB * bt_ppb * NB;
+    for (int P0 = ((npanels - 1) / bt_ppb) * bt_ppb; P0 >= 0; P0 -= bt_ppb) {
+      const int pend = P0 + bt_ppb < npanels ? P0 + bt_ppb : npanels;
+      const int J = P0 * NB, nblk = (pend - P0) * NB, mJ = M - J, nq2 = Lq - J;
+      if (nq2 <= 0) continue;
+      const double* Vb = ws.V + (long)J * ws.ldv + J;
+      const double* Tb = btT + (long)(P0 / bt_ppb) * nbo2;
+      double* Qs = Q + (long)J * Lq + J;
+      ND4_TRY(nd4_gemm(h, true, false, nblk, nq2, mJ, 1.0, Vb, ws.ldv, ws.sV, Qs, Lq, sQ, 0.0, btX, nq2, bt_sX, batch));
+      ND4_TRY(nd4_gemm(h, false, false, nblk, nq2, nblk, 1.0, Tb, nblk, bt_sT, btX, nq2, bt_sX, 0.0, btW, nq2, bt_sX, batch));
+      ND4_TRY(nd4_gemm(h, false, false, mJ, nq2, nblk, -1.0, Vb, ws.ldv, ws.sV, btW, nq2, bt_sX, 1.0, Qs, Lq, sQ, batch));
+    }
   } else {
     ND4_TRY(nd4_set_identity(h, M, Lq, Q, Lq, batch, sQ));
     for (int pnl = npanels - 1; pnl >= 0; pnl--) {
