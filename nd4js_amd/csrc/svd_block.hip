@@ -757,11 +757,12 @@ int nd4_jacobi_block_sweep(nd4hip_handle* h, int batch, int N, double* W, double
       for (int c = 0; c < 2; c++) {
         const int p0 = c * q;
         hipLaunchKernelGGL(jacb_gram2, dim3((unsigned)q, (unsigned)nchunks, 1u), dim3(256), 0, chain[c], W, N, sM, nblk, n2, step, st, Gpart, nchunks, sG, p0);
+        static const int pad2_kb = getenv("ND4HIP_JAC_EIGEN_PAD_KB") ? atoi(getenv("ND4HIP_JAC_EIGEN_PAD_KB")) : 0;
         if (prev_full)
-          hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)q, 1u), dim3(576), 0, chain[c],
+          hipLaunchKernelGGL(jacb_eigen_p, dim3((unsigned)q, 1u), dim3(576), (size_t)pad2_kb * 1024, chain[c],
                              Gpart, nchunks, sG, nblk, n2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, p0);
         else
-          hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(q + q * nchunks), 1u), dim3(576), 0, chain[c],
+          hipLaunchKernelGGL(jacb_eigen_pu, dim3((unsigned)(q + q * nchunks), 1u), dim3(576), (size_t)pad2_kb * 1024, chain[c],
                              Gpart, nchunks, sG, nblk, n2, step, st, floor2, tol2, Qt, sQ, flags, sF, offmax, dense_phase ? 0 : 1, q,
                              Ut, N, sM, Qt2[(step - 1) & 1], flags2[(step - 1) & 1], p0);
         if (phase_end)
