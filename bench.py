@@ -257,7 +257,7 @@ def main():
         # counter figures beside the time-derived fractions of the side ops (same passes, other kernels)
         out["pmc"] = {}
         for rnd in reversed(pmc):
-            for name in ("qr_panel_batched_pmc.json", "qr_lu_2048_pmc.json", "svd_small_pmc.json", "svd2048_pmc.json"):
+            for name in ("qr_panel_batched_pmc.json", "qr_lu_2048_pmc.json", "svd_small_pmc.json", "svd2048_pmc.json", "hess_bidiag_2048_pmc.json"):
                 f = os.path.join(ROOT, "profiles", rnd, name)
                 if name not in out["pmc"] and os.path.exists(f):
                     try:
