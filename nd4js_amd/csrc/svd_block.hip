@@ -436,17 +436,18 @@ __device__ __forceinline__ void eigen_p_body(double* __restrict__ stage_raw, con
     d2 acc[KL];
 #pragma unroll
     for (int k = 0; k < KL; k++) acc[k] = d2{0.0, 0.0};
-    for (int ch0 = 0; ch0 < nchunks; ch0 += 4) {
-      d2 v[4][KL];
+    constexpr int CG = 8;                                    // chunks in flight at once (2048^2 has 8: one memory round trip instead of two)
+    for (int ch0 = 0; ch0 < nchunks; ch0 += CG) {
+      d2 v[CG][KL];
 #pragma unroll
-      for (int c = 0; c < 4; c++)
+      for (int c = 0; c < CG; c++)
 #pragma unroll
         for (int k = 0; k < KL; k++) {
           const int e = 2 * (t + TB * k);                    // the partials hold the ten 16 x 16 tiles on and above the diagonal
           v[c][k] = (ch0 + c < nchunks && ((e / PB) >> 4) <= ((e % PB) >> 4)) ? Gp[(long)(ch0 + c) * (PB * PB / 2) + t + TB * k] : d2{0.0, 0.0};
         }
 #pragma unroll
-      for (int c = 0; c < 4; c++)
+      for (int c = 0; c < CG; c++)
 #pragma unroll
         for (int k = 0; k < KL; k++) acc[k] += v[c][k];
     }
