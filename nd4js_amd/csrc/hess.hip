@@ -509,6 +509,33 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
     if (lane == 0) { s_wm[wave] = wm; s_wS[wave] = wS; }
   }
   __syncthreads();
+  // ---- the reflector's scalars (hessenberg.js:43-56), by every thread in the same order; branch-free (a zero row, :46, is selected
+  // at the end) so that the chain can be scheduled between the FMAs of the tile update that precedes it
+  struct Refl { bool skip; double nrm, vii, inv2, scale; };
+  auto reflector = [&]() -> Refl {
+    const double m1 = fmax(fmax(s_wm[0], s_wm[1]), fmax(s_wm[2], s_wm[3]));
+    const bool skip = m1 == 0.0;                                  // NORM.max === 0 -> continue (:46)
+    const double m1s = skip ? 1.0 : m1;
+    const double i1 = fast_rcp(m1s);
+    double S1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) { const double f = s_wm[g] * i1; S1 += s_wS[g] * f * f; }
+    const double hii0 = s_h0;
+    const double mx = fmax(m1s, fabs(hii0));
+    const double imx = fast_rcp(mx);
+    const double q1 = m1s * imx, q0 = hii0 * imx;
+    const double ss = S1 * q1 * q1 + q0 * q0;
+    const double nrm = (isfinite(mx) ? ss * fast_rsqrt(ss) * mx : mx) * (hii0 > 0 ? -1.0 : 1.0);        // :47
+    const double hii = hii0 - nrm;                                                                        // :48
+    const double mx2 = fmax(m1s, fabs(hii));
+    const double inv2 = fast_rcp(mx2);
+    const double r1 = m1s * inv2, r0 = hii * inv2;
+    const double scale = 1.4142135623730951 * fast_rsqrt(S1 * r1 * r1 + r0 * r0);
+    Refl r;
+    r.skip = skip; r.nrm = skip ? 0.0 : nrm; r.inv2 = skip ? 0.0 : inv2; r.scale = skip ? 0.0 : scale; r.vii = skip ? 0.0 : hii * inv2 * scale;
+    return r;
+  };
+  Refl rf = reflector();
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? (long long)wall_clock64() : 0;   // ND4HIP_HESSP_STAMPS: time per phase (100 MHz ticks), thread 0
 #define HP_STAMP(k) if (stamps) { const long long now = (long long)wall_clock64(); tacc[k] += now - tlast; tlast = now; }
   for (int i = N - 1; i > 1; i--) {
@@ -527,28 +554,9 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
         hp_st(rs, bslot + (2 * T + tc + 16 * b) * 16, x, tag);
       }
     }
-    // ---- the reflector's scalars (hessenberg.js:43-56), by every thread in the same order
-    const double m1 = fmax(fmax(s_wm[0], s_wm[1]), fmax(s_wm[2], s_wm[3]));
-    const bool skip = m1 == 0.0;                                  // NORM.max === 0 -> continue (:46)
-    double nrm = 0.0, vii = 0.0, inv2 = 0.0, scale = 0.0, hii = 0.0;
-    if (!skip) {
-      const double i1 = fast_rcp(m1);
-      double S1 = 0.0;
-#pragma unroll
-      for (int g = 0; g < 4; g++) { const double f = s_wm[g] * i1; S1 += s_wS[g] * f * f; }
-      const double hii0 = s_h0;
-      const double mx = fmax(m1, fabs(hii0));
-      const double imx = fast_rcp(mx);
-      const double q1 = m1 * imx, q0 = hii0 * imx;
-      const double ss = S1 * q1 * q1 + q0 * q0;
-      nrm = (isfinite(mx) ? ss * fast_rsqrt(ss) * mx : mx) * (hii0 > 0 ? -1.0 : 1.0);        // :47
-      hii = hii0 - nrm;                                                                        // :48
-      const double mx2 = fmax(m1, fabs(hii));
-      inv2 = fast_rcp(mx2);
-      const double r1 = m1 * inv2, r0 = hii * inv2;
-      scale = 1.4142135623730951 * fast_rsqrt(S1 * r1 * r1 + r0 * r0);
-      vii = hii * inv2 * scale;
-    }
+    // (the reflector's scalars of this step were computed at the end of the previous one, beside its tile update)
+    const bool skip = rf.skip;
+    const double nrm = rf.nrm, vii = rf.vii, inv2 = rf.inv2, scale = rf.scale;
     double vr[E], vc[E];
 #pragma unroll
     for (int a = 0; a < E; a++) {
@@ -674,14 +682,15 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
     __syncthreads();
     if (s_dead) break;
     HP_STAMP(3)
-    if (!skip) {
+    const Refl rfn = reflector();                                            // the next step's, from what round C brought
+    {                                                                        // (a skipped step published zeros: the update is exact then)
 #pragma unroll
       for (int a = 0; a < E; a++) {
         const double ya = s_y[tr + 16 * a];
 #pragma unroll
         for (int b = 0; b < E; b++) h[a][b] = fma(-vr[a], s_w[tc + 16 * b], fma(-ya, vc[b], h[a][b]));
       }
-      if (p == pi) {                                                       // the finished row (:83-84)
+      if (!skip && p == pi) {                                              // the finished row (:83-84)
 #pragma unroll
         for (int a = 0; a < E; a++)
 #pragma unroll
@@ -691,6 +700,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
           }
       }
     }
+    rf = rfn;
     HP_STAMP(4)
   }
 #undef HP_STAMP
