@@ -9,7 +9,8 @@
 typedef unsigned long long qx_u64;
 // The partners of an exchange are consecutive workgroups of ONE launch and the host only uses it while they all fit on the chip at
 // once (QR: the row workgroups of a panel launch come first in the grid, at most 8 x 33 of 512 threads = one per CU; LU:
-// P x batch <= 64 workgroups), so each partner is resident or next in the dispatch order. HIP does not promise that order, and a GPU
+// P x batch <= 64 workgroups; the one-launch Hessenberg / bidiagonalisation, xchg16.h: exactly 256 workgroups of 256 threads, taken
+// only when the occupancy query says that 256 fit the device's CUs at once), so each partner is resident or next in the dispatch order. HIP does not promise that order, and a GPU
 // shared with other processes may delay a workgroup: every spin is therefore bounded. A stuck exchange ends after about a second
 // (QX_SPIN_LIMIT polls of ~1 us), marks its results (NaN / P = -1) and raises the handle's status word, which the next synchronising
 // entry point turns into ND4HIP_ERR_XCHG.
