@@ -454,6 +454,8 @@ __global__ void bd2_finish_row(double* __restrict__ W, int N, int i, const doubl
 // Only the two diagonals of B, the reflectors and tau leave the kernel. Tags are the step + 1, areas alternate with the parity of
 // the step; rounds 2 and 4 end with every workgroup having read something of every other, so no area is overwritten before it
 // has been read. Every spin is bounded (time-out: abort flag for all workgroups, ND4HIP_ERR_XCHG at the next synchronising call).
+constexpr unsigned BP_NREP = 8;                                                    // copies of the arrays everybody reads (see HP_NREP in xchg16.h); 2048^2: 1 / 4 / 8 / 16 copies 27.8 / 27.7 / 27.4 / 28.2 ms
+constexpr unsigned BP_REP_A2 = 2 * 256 * 3 * 16, BP_REP_A4 = 2 * 256 * 2 * 16;    // bytes per copy
 struct BdPx {
   qx_u64* base;
   unsigned o1, o2, o3, o4;   // [2][256][3T | 2E | T | 2E] values (byte offsets)
@@ -514,7 +516,8 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
     const bool more = first < K;
     const unsigned R1p = X.o1 + (unsigned)par * 256 * V1 * 16, R2p = X.o2 + (unsigned)par * 256 * V2 * 16;
     const unsigned R3p = X.o3 + (unsigned)par * 256 * V3 * 16, R4p = X.o4 + (unsigned)par * 256 * V4 * 16;
-    const unsigned A2p = X.oA2 + (unsigned)par * 256 * 3 * 16, A4p = X.oA4 + (unsigned)par * 256 * 2 * 16;
+    const unsigned A2p = X.oA2 + (unsigned)par * 256 * 3 * 16, A4p = X.oA4 + (unsigned)par * 256 * 2 * 16;     // copy 0; the copies are BP_REP_A2 / _A4 bytes apart
+    const unsigned A2r = A2p + (unsigned)(wg % BP_NREP) * BP_REP_A2, A4r = A4p + (unsigned)(wg % BP_NREP) * BP_REP_A4;   // the copy this workgroup reads
     const unsigned slot1 = R1p + (unsigned)wg * V1 * 16;
     // row i and column i+1 as they stand, by the lanes that hold them
     if (p == pi && tr == (li & 15)) {
@@ -614,7 +617,9 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       const unsigned slot2 = R2p + (unsigned)wg * V2 * 16;
       hp_st(rs, slot2 + c * 16, z, tag);
       hp_st(rs, slot2 + (E + c) * 16, r, tag);
-      if (c == 0) { hp_st(rs, A2p + (wg * 3) * 16, m, tag); hp_st(rs, A2p + (wg * 3 + 1) * 16, ss, tag); hp_st(rs, A2p + (wg * 3 + 2) * 16, zr, tag); }
+      for (int r = c; r < (int)BP_NREP; r += E) {                          // (the E lanes all hold the reduced values: lane c writes the copies c, c + E, ...)
+        hp_st(rs, A2p + r * BP_REP_A2 + (wg * 3) * 16, m, tag); hp_st(rs, A2p + r * BP_REP_A2 + (wg * 3 + 1) * 16, ss, tag); hp_st(rs, A2p + r * BP_REP_A2 + (wg * 3 + 2) * 16, zr, tag);
+      }
     }
     // ---- round 2: z and r over the columns q, the partials of everybody, the entries at column i+1
     {
@@ -623,9 +628,9 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       const unsigned src = R2p + (unsigned)((((t / E) & 15) * 16 + q) * V2) * 16;
       rq[0] = HpReq{src + (t % E) * 16, t < T};
       rq[1] = HpReq{src + (E + t % E) * 16, t < T};
-      rq[2] = HpReq{A2p + (unsigned)(t * 3) * 16, true};
-      rq[3] = HpReq{A2p + (unsigned)(t * 3 + 1) * 16, true};
-      rq[4] = HpReq{A2p + (unsigned)(t * 3 + 2) * 16, true};
+      rq[2] = HpReq{A2r + (unsigned)(t * 3) * 16, true};
+      rq[3] = HpReq{A2r + (unsigned)(t * 3 + 1) * 16, true};
+      rq[4] = HpReq{A2r + (unsigned)(t * 3 + 2) * 16, true};
       const int ef = first < N ? first : i, jf = ef % T;
       const unsigned srcf = R2p + (unsigned)(((jf / E) * 16 + ef / T) * V2) * 16;
       rq[5] = HpReq{srcf + (E + jf % E) * 16, t == 0};
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       const unsigned slot4 = R4p + (unsigned)wg * V4 * 16;
       hp_st(rs, slot4 + c * 16, y, tag);
       hp_st(rs, slot4 + (E + c) * 16, cn, tag);
-      if (c == 0) { hp_st(rs, A4p + (wg * 2) * 16, m, tag); hp_st(rs, A4p + (wg * 2 + 1) * 16, ss, tag); }
+      for (int r = c; r < (int)BP_NREP; r += E) { hp_st(rs, A4p + r * BP_REP_A4 + (wg * 2) * 16, m, tag); hp_st(rs, A4p + r * BP_REP_A4 + (wg * 2 + 1) * 16, ss, tag); }
     }
     // ---- round 4: y and the next column over the rows p, the norm partials of everybody, the next diagonal entry
     {
@@ -742,8 +747,8 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
       const unsigned src = R4p + (unsigned)((p * 16 + ((t / E) & 15)) * V4) * 16;
       rq[0] = HpReq{src + (t % E) * 16, t < T};
       rq[1] = HpReq{src + (E + t % E) * 16, t < T};
-      rq[2] = HpReq{A4p + (unsigned)(t * 2) * 16, true};
-      rq[3] = HpReq{A4p + (unsigned)(t * 2 + 1) * 16, true};
+      rq[2] = HpReq{A4r + (unsigned)(t * 2) * 16, true};
+      rq[3] = HpReq{A4r + (unsigned)(t * 2 + 1) * 16, true};
       rq[4] = HpReq{R4p + (unsigned)((q1 * 16 + l1 / E) * V4 + E + l1 % E) * 16, t == 0};       // row i+1: block q1, local l1
       hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay & 255);
       if (t < T) { s_y[t] = xv[0]; s_cu[t] = xv[1]; }
@@ -839,7 +844,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     // ---- one launch: 16 x 16 workgroups keep the matrix in registers for the whole reduction (see bdp) ----
     const int E = mx <= 512 ? 2 : (mx <= 1024 ? 4 : 8), T = 16 * E;
     const size_t V1 = 3 * T, V2 = 2 * E, V3 = T, V4 = 2 * E;
-    const size_t xbytes = 16 * 2 * 256 * (V1 + V2 + V3 + V4 + 3 + 2);
+    const size_t xbytes = 16 * 2 * 256 * (V1 + V2 + V3 + V4) + (size_t)BP_NREP * (BP_REP_A2 + BP_REP_A4);
     Nd4WsScope scope2(h);
     void* qp = nullptr;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)K * M + xbytes + 64, &qp));
@@ -847,7 +852,7 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     BdPx X;
     X.base = reinterpret_cast<qx_u64*>(ULt + (size_t)K * M);
     X.o1 = 0; X.o2 = X.o1 + (unsigned)(2 * 256 * V1 * 16); X.o3 = X.o2 + (unsigned)(2 * 256 * V2 * 16); X.o4 = X.o3 + (unsigned)(2 * 256 * V3 * 16);
-    X.oA2 = X.o4 + (unsigned)(2 * 256 * V4 * 16); X.oA4 = X.oA2 + 2 * 256 * 3 * 16; X.bytes = X.oA4 + 2 * 256 * 2 * 16;
+    X.oA2 = X.o4 + (unsigned)(2 * 256 * V4 * 16); X.oA4 = X.oA2 + BP_NREP * BP_REP_A2; X.bytes = X.oA4 + BP_NREP * BP_REP_A4;
     X.abort = reinterpret_cast<int*>(reinterpret_cast<char*>(X.base) + xbytes);
     ND4_HIP(hipMemsetAsync(X.base, 0, xbytes + 64, h->stream));
     static const bool want_stamps = getenv("ND4HIP_BDP_STAMPS") != nullptr;

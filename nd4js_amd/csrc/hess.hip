@@ -457,6 +457,7 @@ __global__ void hess_init_u(double* __restrict__ Um, int N) {
 // Every spin is bounded; a time-out raises the handle's status word and an abort flag that ends every workgroup
 // (ND4HIP_ERR_XCHG at the next synchronising call). The scalars of the reflector use the few-ulp reciprocal / reciprocal square
 // root of dpp.h: an IEEE division is ~35 dependent instructions and the chain is the step.
+constexpr unsigned HP_REP_BV = 2 * 256 * 16, HP_REP_CN = 2 * 512 * 16;         // bytes per copy of the arrays everybody reads (HP_NREP copies, xchg16.h)
 struct HessPx {
   qx_u64* base;          // one buffer: every value that crosses is a 16-byte pair of tagged words, stored and loaded as ONE access
   unsigned oB, oC;       // [2][256][3T | 3E] values: what a workgroup publishes for its row / column partners (byte offsets)
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
     HP_STAMP(1)
     if (t < T) hp_st(rs, bslot + t * 16, skip ? 0.0 : (s_xp[0][t] + s_xp[1][t]) + (s_xp[2][t] + s_xp[3][t]), tag);
     else if (t < 2 * T) hp_st(rs, bslot + t * 16, skip ? 0.0 : s_yp[t - T], tag);
-    if (t == 0) hp_st(rs, X.oBv + (par * 256 + wg) * 16, skip ? 0.0 : (s_vy[0] + s_vy[1]) + (s_vy[2] + s_vy[3]), tag);
+    if (t < HP_NREP) hp_st(rs, X.oBv + t * HP_REP_BV + (par * 256 + wg) * 16, skip ? 0.0 : (s_vy[0] + s_vy[1]) + (s_vy[2] + s_vy[3]), tag);
     // the 16 partials of this workgroup's E columns of x and E rows of y, all 256 partials of v^T y, the 16 partials of y at row
     // i-1 and this workgroup's E columns of row i-1
     {
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
       double xv[3] = {0.0, 0.0, 0.0};
       if (t < 16 * E) rq[0] = HpReq{Bp + (unsigned)(((t / E) * 16 + q) * BV + E * p + t % E) * 16, true};
       else { const int u = t - 16 * E; rq[0] = HpReq{Bp + (unsigned)((p * 16 + u / E) * BV + T + E * q + u % E) * 16, t < 32 * E}; }
-      rq[1] = HpReq{X.oBv + (unsigned)(par * 256 + t) * 16, true};
+      rq[1] = HpReq{X.oBv + (unsigned)(wg % HP_NREP) * HP_REP_BV + (unsigned)(par * 256 + t) * 16, true};
       if (t < 16) rq[2] = HpReq{Bp + (unsigned)((pn * 16 + t) * BV + T + ln) * 16, true};
       else rq[2] = HpReq{Bp + (unsigned)((pn * 16 + q) * BV + 2 * T + E * p + (t - 16)) * 16, t < 16 + E};
       hp_wait<3>(rs, rq, xv, tag, dead, X.abort, status, delay >> 8);
@@ -649,7 +650,8 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
         if constexpr (E >= 8) ss += xor4(ss);
         hp_st(rs, cslot + c * 16, w, tag);
         hp_st(rs, cslot + (2 * E + c) * 16, rn, tag);
-        if (c == 0) { hp_st(rs, X.oCn + (par * 512 + 2 * wg) * 16, m, tag); hp_st(rs, X.oCn + (par * 512 + 2 * wg + 1) * 16, ss, tag); }
+        // (the E lanes all hold the reduced m and ss: lane c writes the copies c, c + E, ...)
+        for (int r = c; r < (int)HP_NREP; r += E) { hp_st(rs, X.oCn + r * HP_REP_CN + (par * 512 + 2 * wg) * 16, m, tag); hp_st(rs, X.oCn + r * HP_REP_CN + (par * 512 + 2 * wg + 1) * 16, ss, tag); }
       } else {
         hp_st(rs, cslot + (E + c) * 16, (T * p + E * q + c < i) ? s : 0.0, tag);      // y, rows < i only
       }
@@ -666,8 +668,8 @@ __global__ __launch_bounds__(256) void hessp(double* __restrict__ H, int N, doub
         rq[0] = HpReq{Cp + (unsigned)((p * 16 + j / E) * CV + E + j % E) * 16, t < 2 * T};
         rq[1] = HpReq{Cp + (unsigned)(((j / E) * 16 + p) * CV + 2 * E + j % E) * 16, t < 2 * T};
       }
-      rq[2] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t) * 16, true};
-      rq[3] = HpReq{X.oCn + (unsigned)(par * 512 + 2 * t + 1) * 16, true};
+      rq[2] = HpReq{X.oCn + (unsigned)(wg % HP_NREP) * HP_REP_CN + (unsigned)(par * 512 + 2 * t) * 16, true};
+      rq[3] = HpReq{X.oCn + (unsigned)(wg % HP_NREP) * HP_REP_CN + (unsigned)(par * 512 + 2 * t + 1) * 16, true};
       { const int e = ii - 1 < 0 ? 0 : ii - 1, j = e % T; rq[4] = HpReq{Cp + (unsigned)(((j / E) * 16 + e / T) * CV + 2 * E + j % E) * 16, t == 0}; }
       hp_wait<5>(rs, rq, xv, tag, dead, X.abort, status, delay & 255);
       if (t < T) { s_w[t] = xv[0]; s_rc[t] = xv[1]; }
@@ -764,14 +766,14 @@ int nd4_gehrd(nd4hip_handle* h, int64_t batch64, int64_t N64, const double* A, d
     // ---- one launch: 16 x 16 workgroups keep H in registers for the whole reduction (see hessp) ----
     const int E = N <= 512 ? 2 : (N <= 1024 ? 4 : 8), T = 16 * E;
     const size_t BV = 3 * T, CV = 3 * E;                                                    // values (16 bytes each) per slot
-    const size_t xwords = 2 * (2 * 256 * (BV + CV) + 2 * 256 + 2 * 512);
+    const size_t xwords = 2 * (2 * 256 * (BV + CV)) + (size_t)HP_NREP * (HP_REP_BV + HP_REP_CN) / 8;
     void* q = nullptr;
     ND4_TRY(nd4_ws_alloc(h, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, &q));
     double* vrows = static_cast<double*>(q);
     HessPx X;
     X.base = reinterpret_cast<qx_u64*>(vrows + (size_t)nstore * N);
-    X.oB = 0; X.oC = (unsigned)(2 * 256 * BV * 16); X.oBv = X.oC + (unsigned)(2 * 256 * CV * 16); X.oCn = X.oBv + 2 * 256 * 16;
-    X.bytes = X.oCn + 2 * 512 * 16;
+    X.oB = 0; X.oC = (unsigned)(2 * 256 * BV * 16); X.oBv = X.oC + (unsigned)(2 * 256 * CV * 16); X.oCn = X.oBv + HP_NREP * HP_REP_BV;
+    X.bytes = X.oCn + HP_NREP * HP_REP_CN;
     X.abort = reinterpret_cast<int*>(X.base + xwords);
     ND4_HIP(hipMemsetAsync(vrows, 0, sizeof(double) * (size_t)nstore * N + sizeof(qx_u64) * xwords + 64, h->stream));
     const int drop = nd4_test_drop_panel() >= 0 ? N - 1 - nd4_test_drop_panel() : -1;       // test hook: row N-1-k is never published

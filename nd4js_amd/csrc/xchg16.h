@@ -7,6 +7,10 @@
 #include "xchg.h"
 #include "dpp.h"
 
+// The arrays that EVERY workgroup reads (one or a few values per workgroup: partial dot products, norm partials) are kept in HP_NREP
+// copies, written by their owners' lanes and read as copy (workgroup % HP_NREP): 256 readers of the same few lines meet in the
+// same memory channels (Hessenberg 2048^2: 1 / 8 / 16 / 32 copies 19.8 / 18.9 / 18.3 / 18.3 ms).
+constexpr unsigned HP_NREP = 16;
 struct HpReq { unsigned off; bool on; };
 typedef unsigned int hp_u4 __attribute__((ext_vector_type(4)));
 
