@@ -409,6 +409,8 @@ __global__ __launch_bounds__(2048 / PW) void jacb_eigen(const double* __restrict
 // with, so G stays consistent with the accumulated Q.
 // Angle formulas: c^2 = (1 + |d|/root)/2, s = g/(root*c), t = s/c, tau = s/(1+c) with d = b - a, root = sqrt(d^2 + 4 g^2): two
 // rsqrt chains and one rcp chain, no IEEE division.
+template <int CG>   // chunks of partial Gram matrices in flight at once: 8 for one large matrix (one memory round trip at 2048^2), 4 for batches (86
+                    // instead of 150 VGPRs: two workgroups per CU, which is what the throughput-bound batches need: 1024 x 512^2 0.69 -> 0.59 s)
 __device__ __forceinline__ void eigen_p_body(double* __restrict__ stage_raw, const int pairIdx, const int mat,
                                              const double* __restrict__ Gpart, int nchunks, long sG_mat, int nblk, int nblk2, int step,
                                              JacState* __restrict__ st, const double* __restrict__ floor2, double tol2,
@@ -436,7 +438,6 @@ __device__ __forceinline__ void eigen_p_body(double* __restrict__ stage_raw, con
     d2 acc[KL];
 #pragma unroll
     for (int k = 0; k < KL; k++) acc[k] = d2{0.0, 0.0};
-    constexpr int CG = 8;                                    // chunks in flight at once (2048^2 has 8: one memory round trip instead of two)
     for (int ch0 = 0; ch0 < nchunks; ch0 += CG) {
       d2 v[CG][KL];
 #pragma unroll
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(576) void jacb_eigen_p(const double* __restrict__ G
                                                      double* __restrict__ Qt_all, long sQ_mat, int* __restrict__ flags, long sF_mat,
                                                      unsigned long long* __restrict__ offmax, int precheck, int pair0) {
   __shared__ double stage_raw[STAGE_DOUBLES];
-  eigen_p_body(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+  eigen_p_body<4>(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
                offmax, precheck);
 }
 
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(576) void jacb_eigen_pu(const double* __restrict__ 
                                                       const int* __restrict__ flags_prev, int pair0) {
   __shared__ double stage_raw[STAGE_DOUBLES];
   if ((int)blockIdx.x < npairs) {
-    eigen_p_body(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
+    eigen_p_body<8>(stage_raw, blockIdx.x + pair0, blockIdx.y, Gpart, nchunks, sG_mat, nblk, nblk2, step, st, floor2, tol2, Qt_all, sQ_mat, flags, sF_mat,
                  offmax, precheck);
   } else {
     const int idx = (int)blockIdx.x - npairs;
