@@ -466,7 +466,7 @@ struct BdPx {
 
 template <int E>
 __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N, int K, double* __restrict__ ULt, double* __restrict__ tauL,
-                                            double* __restrict__ VR, int* __restrict__ flagR, BdPx X, int* status, int delay, long long* stamps) {
+                                            double* __restrict__ VR, int* __restrict__ flagR, BdPx X, int* status, int delay, long long* stamps, int drop_step) {
   using namespace nd4dpp;
   constexpr int T = 16 * E, V1 = 3 * T, V2 = 2 * E, V3 = T, V4 = 2 * E;
   constexpr int LE = E == 8 ? 3 : (E == 4 ? 2 : 1);                 // log2 E
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void bdp(double* __restrict__ W, int M, int N,
     const unsigned A2r = A2p + (unsigned)(wg % BP_NREP) * BP_REP_A2, A4r = A4p + (unsigned)(wg % BP_NREP) * BP_REP_A4;   // the copy this workgroup reads
     const unsigned slot1 = R1p + (unsigned)wg * V1 * 16;
     // row i and column i+1 as they stand, by the lanes that hold them
-    if (p == pi && tr == (li & 15)) {
+    if (p == pi && tr == (li & 15) && i != drop_step) {                 // (drop_step: tests only, ND4HIP_TEST_DROP_PUBLISH: row never published)
 #pragma unroll
       for (int bi = 0; bi < E; bi++) {
         double x = 0.0;
@@ -860,9 +860,9 @@ int nd4_gebrd(nd4hip_handle* h, int64_t batch64, int64_t M64, int64_t N64, const
     const int delay = getenv("ND4HIP_BDP_DELAY") ? atoi(getenv("ND4HIP_BDP_DELAY")) : (0 << 8 | 4);
     long long* stamps = nullptr;
     if (want_stamps) { void* sp = nullptr; ND4_TRY(nd4_ws_alloc(h, sizeof(long long) * 256 * 8, &sp)); stamps = static_cast<long long*>(sp); }
-    if (E == 2) hipLaunchKernelGGL(bdp<2>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
-    else if (E == 4) hipLaunchKernelGGL(bdp<4>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
-    else hipLaunchKernelGGL(bdp<8>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps);
+    if (E == 2) hipLaunchKernelGGL(bdp<2>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps, nd4_test_drop_panel());
+    else if (E == 4) hipLaunchKernelGGL(bdp<4>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps, nd4_test_drop_panel());
+    else hipLaunchKernelGGL(bdp<8>, dim3(256), dim3(256), 0, h->stream, W, M, N, K, ULt, tauL, VR, flagR, X, h->xstat, delay, stamps, nd4_test_drop_panel());
     ND4_HIP(hipGetLastError());
     if (stamps) {                                     // per step, in us: left reflector | round 1 | sums + round 2 | right reflector | round 3 | sums + round 4 | update
       long long hs[256 * 8];

@@ -147,9 +147,9 @@ import numpy as np
 from nd4js_amd import la, rng, _lib
 kind, panel = sys.argv[2], sys.argv[3]
 # QR: the row-split panels of one matrix; LU: the multi-workgroup panels (N > 2048); Hessenberg: the one-launch reduction (N <= 2048)
-N = {"qr": 2048, "lu": 4096, "hess": 1024}[kind]
+N = {"qr": 2048, "lu": 4096, "hess": 1024, "bidiag": 1024}[kind]
 a = rng.matrix(9901, N, N)
-fn = {"qr": la.qr_decomp, "lu": la.lu_decomp, "hess": la.hessenberg_decomp}[kind]
+fn = {"qr": la.qr_decomp, "lu": la.lu_decomp, "hess": la.hessenberg_decomp, "bidiag": la.bidiag_decomp}[kind]
 fn(a)                                                # warm: code objects, workspace
 os.environ["ND4HIP_TEST_DROP_PUBLISH"] = panel       # read per call: one workgroup of that panel skips one publication
 t0 = time.perf_counter()
@@ -166,6 +166,9 @@ if kind == "qr":
 elif kind == "hess":
     u, hh = out
     ok = np.abs(u @ hh @ u.T - a).max() <= 1e-10 and np.abs(np.tril(hh, -2)).max() == 0.0
+elif kind == "bidiag":
+    u, b, v = out
+    ok = np.abs(u @ b @ v - a).max() <= 1e-10 and np.abs(np.tril(b, -1)).max() == 0.0 and np.abs(np.triu(b, 2)).max() == 0.0
 else:
     lu, p = out
     l, u = np.tril(lu, -1) + np.eye(N), np.triu(lu)
@@ -175,10 +178,10 @@ print("AFTER", "OK" if ok else "BAD")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,panel", [("qr", 3), ("lu", 2), ("hess", 5)])
+@pytest.mark.parametrize("kind,panel", [("qr", 3), ("lu", 2), ("hess", 5), ("bidiag", 7)])
 def test_a_stuck_in_kernel_exchange_is_an_error(tmp_path, kind, panel):
     """VERDICT r3 #3 / ADVICE r3: the tagged-word exchanges between co-resident workgroups (xchg.h: the row-split QR panels, the
-    multi-workgroup LU panels, the one-launch Hessenberg reduction) bound every spin; a partner that never publishes used to leave NaN / P = -1 behind a return code
+    multi-workgroup LU panels, the one-launch Hessenberg reduction and bidiagonalisation) bound every spin; a partner that never publishes used to leave NaN / P = -1 behind a return code
     of 0. Now the kernels raise a per-handle status word and every synchronising entry point returns ND4HIP_ERR_XCHG (-6). The
     test-only switch ND4HIP_TEST_DROP_PUBLISH=<panel> makes one workgroup skip one publication, so that the path runs once: the
     call fails within a few seconds with that code, and the same handle factorises correctly afterwards. (Child process: the
