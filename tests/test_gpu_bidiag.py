@@ -124,3 +124,24 @@ def test_fused_path_below_the_one_launch_cap(la, M, N, monkeypatch):
     if M * N <= 300 * 300:
         uo, bo, vo = oracle.bidiag_decomp(a)
         assert np.abs(b - bo).max() <= 1e-11 * max(M, N) and np.abs(u - uo).max() <= 1e-10 and np.abs(v - vo).max() <= 1e-10
+
+
+def test_one_launch_reduction_special_inputs(la):
+    """As tests/test_gpu_hess.py::test_one_launch_reduction_special_inputs, for bdp: zeros, identity, 1e150 / 1e-150 / 1e-290 scales,
+    rank 8, zero rows and columns, an already bidiagonal input, a graded matrix."""
+    N = 256
+    base = rng.matrix(7800, N, N)
+    zc = base.copy()
+    zc[:, 5] = 0.0
+    zc[17, :] = 0.0
+    zc[:, 200:210] = 0.0
+    cases = {"zeros": np.zeros((N, N)), "identity": np.eye(N), "1e150": base * 1e150, "1e-150": base * 1e-150, "1e-290": base * 1e-290,
+             "lowrank": rng.matrix(7801, N, 8) @ rng.matrix(7802, 8, N), "zero rows and columns": zc,
+             "upper bidiagonal": np.triu(np.tril(base, 1)), "graded": base * np.logspace(0, -12, N)[:, None]}
+    for name, a in cases.items():
+        sc = max(np.abs(a).max(), 1e-300)
+        u, b, v = la.bidiag_decomp(a)
+        assert np.isfinite(b).all() and np.isfinite(u).all() and np.isfinite(v).all(), name
+        assert np.abs(u @ b @ v - a).max() <= 256 * EPS * N * sc, name
+        assert np.abs(u.T @ u - np.eye(N)).max() <= 16 * EPS * N and np.abs(v @ v.T - np.eye(N)).max() <= 16 * EPS * N, name
+        assert np.abs(np.tril(b, -1)).max() == 0.0 and np.abs(np.triu(b, 2)).max() == 0.0, name

@@ -144,3 +144,28 @@ def test_blocked_path_beyond_the_one_launch_reduction(la):
     a = rng.matrix(6800, N, N)
     u, h = la.hessenberg_decomp(a)
     check_props(a, u, h)
+
+
+def _special_inputs(N, seed):
+    base = rng.matrix(seed, N, N)
+    zc = base.copy()
+    zc[:, 5] = 0.0
+    zc[17, :] = 0.0
+    zc[:, 200:210] = 0.0
+    return {"zeros": np.zeros((N, N)), "identity": np.eye(N), "1e150": base * 1e150, "1e-150": base * 1e-150, "1e-290": base * 1e-290,
+            "lowrank": rng.matrix(seed + 1, N, 8) @ rng.matrix(seed + 2, 8, N), "zero rows and columns": zc,
+            "upper hessenberg": np.triu(base, -1), "graded": base * np.logspace(0, -12, N)[:, None]}
+
+
+def test_one_launch_reduction_special_inputs(la):
+    """The one-launch reduction scales every norm by the largest entry it sees (per 8-column group, then across the workgroups) and
+    uses few-ulp reciprocals in the reflector's scalars: no overflow at 1e150, no underflow at 1e-290, zero rows are skipped
+    (hessenberg.js:46), rank-deficient and graded inputs keep the reference's properties relative to the input's scale."""
+    N = 256
+    for name, a in _special_inputs(N, 6900).items():
+        sc = max(np.abs(a).max(), 1e-300)
+        u, h = la.hessenberg_decomp(a)
+        assert np.isfinite(h).all() and np.isfinite(u).all(), name
+        assert np.abs(u @ h @ u.T - a).max() <= 256 * EPS * N * sc, name
+        assert np.abs(u @ u.T - np.eye(N)).max() <= 16 * EPS * N, name
+        assert np.abs(np.tril(h, -2)).max() == 0.0, name
