@@ -33,8 +33,9 @@ typedef struct nd4hip_handle nd4hip_handle;
 #define ND4HIP_ERR_NODEV    -4   /* no usable GPU */
 #define ND4HIP_ERR_SINGULAR -5   /* Cholesky met a NaN pivot: 'Matrix contains NaNs or is (near) singular.' */
 #define ND4HIP_ERR_XCHG     -6   /* an exchange between co-resident workgroups INSIDE a kernel timed out (the row-split QR panels, the
-                                    multi-workgroup LU panels): the results of the call are invalid — Q / R hold NaN, the permutation
-                                    vector of an LU holds -1 — and the handle stays usable. Reported by the next entry point that
+                                    multi-workgroup LU panels, the one-launch Hessenberg reduction / bidiagonalisation of one matrix of
+                                    128 .. 2048 rows and columns): the results of the call are invalid — Q / R hold NaN, the permutation
+                                    vector of an LU holds -1, U / H / B / V are unspecified — and the handle stays usable. Reported by the next entry point that
                                     synchronises: every host-pointer form, nd4hip_synchronize, nd4hip_timer_stop. The _dev forms
                                     enqueue only and return 0; their callers see the NaN / -1 markers or the code at the next
                                     nd4hip_synchronize. (The reference never returns a half-valid factorisation: lu.js:24-81.) */
@@ -150,14 +151,17 @@ int nd4hip_dldltrs_batched    (nd4hip_handle* h, int64_t batch, int64_t N, int64
 /* ---- bidiag_decomp: replaces src/la/bidiag.js:245-319 (kernels :32-242) -----------------------------------
  * A [batch,M,N] -> U [batch,M,K], B [batch,K,J] upper bidiagonal (exact zeros elsewhere), V [batch,J,N] with A = U B V,
  * K = min(M,N), J = K for M >= N and K+1 for M < N; U has orthonormal columns, V orthonormal rows. The signs follow
- * the reference's three branches (see csrc/bidiag.hip), so U, B, V agree with it to rounding. */
+ * the reference's three branches (see csrc/bidiag.hip), so U, B, V agree with it to rounding. One matrix with 128 <= M, N <= 2048
+ * is reduced by ONE launch whose 256 workgroups exchange inside the kernel (csrc/bidiag.hip: bdp): ND4HIP_ERR_XCHG applies. */
 int nd4hip_dgebrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V);
 int nd4hip_dgebrd_batched    (nd4hip_handle* h, int64_t batch, int64_t M, int64_t N, const double* A, double* U, double* B, double* V);
 
 /* ---- hessenberg_decomp: replaces src/la/hessenberg.js:89-115 (kernel :27-86) -------------------------------
  * A [batch,N,N] -> U, H [batch,N,N] with A = U H U^T, U orthogonal (last row and column = unit vector), H upper
  * Hessenberg with exact zeros below the sub-diagonal. Same reflectors as the reference (rows finished from the bottom
- * up, sign chosen against cancellation), so U and H agree with it to rounding. H may alias A in the _dev form. */
+ * up, sign chosen against cancellation), so U and H agree with it to rounding. H may alias A in the _dev form. One matrix with
+ * 128 <= N <= 2048 is reduced by ONE launch whose 256 workgroups exchange inside the kernel (csrc/hess.hip: hessp): ND4HIP_ERR_XCHG
+ * applies. */
 int nd4hip_dgehrd_batched_dev(nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H);
 int nd4hip_dgehrd_batched    (nd4hip_handle* h, int64_t batch, int64_t N, const double* A, double* U, double* H);
 
